@@ -1,0 +1,166 @@
+/*
+ * mi355pt.h — C ABI of the MI355X-native spectral path-tracing integrator.
+ *
+ * The reference (MatchaChoco010/toy-cpu-pathtracing) has no FFI: it is one generic Rust
+ * binary.  The seam this library drops in behind is
+ *     RendererImage::<R>::render::<S>()          renderer/src/renderer.rs:120-134
+ * i.e. the rayon loop that calls BaseSrgbRenderer::render(p) for every pixel
+ * (renderer/src/renderer/base_renderer.rs:146-280) against an already built
+ * &Scene (scene/src/scene.rs:36-76) and &Camera (renderer/src/camera.rs:14-92).
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions: every function returns 0 on success or a negative MI355PT_E_* code and
+ * never unwinds; input buffers are borrowed for the duration of the call and copied;
+ * all floats are IEEE binary32, all matrices column-major (glam::Mat4 layout).
+ * The library requires a gfx950 device: there is no CPU fallback.
+ */
+#ifndef MI355PT_H
+#define MI355PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355PT_OK 0
+#define MI355PT_E_INVALID (-1)   /* bad argument / bad id / wrong call order */
+#define MI355PT_E_DEVICE (-2)    /* HIP error (see mi355pt_last_error)         */
+#define MI355PT_E_NOT_BUILT (-3) /* scene used before mi355pt_scene_build      */
+#define MI355PT_E_NO_DEVICE (-4) /* no gfx950 device / HIP runtime unavailable */
+
+#define MI355PT_NONE 0xffffffffu
+
+typedef struct mi355pt_scene mi355pt_scene; /* opaque; replaces scene::Scene<Id> (scene/src/scene.rs:36-41) */
+
+/* ---- spectra: spectrum::Spectrum / scene::SpectrumParameter (scene/src/material/parameter.rs:13-47) ---- */
+enum {
+    MI355PT_SPEC_CONSTANT = 0,            /* ConstantSpectrum::new(c[0])            spectrum/constant_spectrum.rs */
+    MI355PT_SPEC_RGB_ALBEDO_SRGB = 1,     /* RgbAlbedoSpectrum<ColorSrgb>::new(c)   spectrum/rgb_albedo_spectrum.rs (needs the table) */
+    MI355PT_SPEC_LUT470 = 2,              /* DenselySampledSpectrum, id from add_lut470 (presets::cie_illum_d6500(), glass_sf11_eta(), ...) */
+    MI355PT_SPEC_TEXTURE_ALBEDO_SRGB = 3, /* SpectrumParameter::texture(RgbTexture::load_srgb, SpectrumType::Albedo), id from add_tex_rgb8 */
+    MI355PT_SPEC_SIGMOID = 4              /* explicit sigmoid-polynomial coefficients c0,c1,c2 (rgb_sigmoid_polynomial.rs:179-182) */
+};
+typedef struct mi355pt_spectrum {
+    uint32_t kind;
+    uint32_t id;
+    float c[3];
+} mi355pt_spectrum;
+
+/* ---- materials: scene::{LambertMaterial, EmissiveMaterial, GlassMaterial, PlasticMaterial,
+ *      SimpleClearcoatPbrMaterial}::new  (scene/src/material/impls/) ---- */
+enum {
+    MI355PT_MAT_LAMBERT = 0,   /* color = albedo, normal_tex                       lambert_material.rs:17-27   */
+    MI355PT_MAT_EMISSIVE = 1,  /* color = radiance, intensity                      emissive_material.rs:17-29  */
+    MI355PT_MAT_GLASS = 2,     /* eta (LUT470), normal_tex, thin, roughness        glass_material.rs:34-49     */
+    MI355PT_MAT_PLASTIC = 3,   /* eta (constant), color, normal_tex, thin, rough.  plastic_material.rs:17-38    */
+    MI355PT_MAT_CLEARCOAT = 4  /* simple_pbr_clearcoat_material.rs:17-75                                       */
+};
+typedef struct mi355pt_material_desc {
+    uint32_t type;
+    mi355pt_spectrum color;
+    uint32_t normal_tex;    /* MI355PT_NONE = NormalParameter::none() */
+    uint32_t normal_flip_y; /* NormalTexture::load(path, flip_y)      */
+    float intensity;        /* Emissive FloatParameter::constant      */
+    mi355pt_spectrum eta;
+    uint32_t thin;
+    float roughness;
+    /* clearcoat only: SimpleClearcoatPbrMaterial::new(base_color=color, metallic, roughness, normal, ior,
+     * clearcoat_ior, clearcoat_roughness, clearcoat_tint, clearcoat_thickness) */
+    float metallic, ior, clearcoat_ior, clearcoat_roughness, clearcoat_thickness;
+    mi355pt_spectrum clearcoat_tint;
+} mi355pt_material_desc;
+
+/* ---- camera: renderer::Camera::new + set_look_to (renderer/src/camera.rs:27-49) ---- */
+typedef struct mi355pt_camera {
+    float position[3];  /* world space */
+    float direction[3]; /* normalised by the library, as set_look_to does */
+    float up[3];
+    float fov_deg; /* vertical; main.rs:68 fixes 45 */
+    uint32_t width, height;
+} mi355pt_camera;
+
+/* ---- renderer arguments: RendererArgs + CLI flags (renderer.rs:84-90, main.rs:20-53) ---- */
+enum { MI355PT_STRATEGY_PT = 0, MI355PT_STRATEGY_NEE = 1, MI355PT_STRATEGY_MIS = 2 };
+enum { MI355PT_SAMPLER_RANDOM = 0, MI355PT_SAMPLER_SOBOL = 1 };
+typedef struct mi355pt_params {
+    uint32_t spp;       /* --spp        */
+    uint32_t seed;      /* --seed       */
+    uint32_t max_depth; /* --max-depth  */
+    uint32_t strategy;  /* --renderer pt|nee|mis */
+    uint32_t sampler;   /* --sampler random|sobol */
+    float exposure;     /* main.rs:191 fixes 1.0; tone map is Reinhard (main.rs:192) */
+    /* multi-GPU sharding of the pixel loop (renderer.rs:121): this call renders only the 8x8
+     * pixel tiles t with t % shard_count == shard_index; other pixels are left untouched. */
+    uint32_t shard_index, shard_count; /* 0,1 (or 0,0) = whole frame */
+    uint32_t collect_stats;            /* 1 = run the instrumented kernel variant and fill mi355pt_stats */
+} mi355pt_params;
+
+typedef struct mi355pt_stats {
+    uint64_t samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;
+    uint64_t closest_hits, bounces, spectrum_evals, textured_lookups;
+    double kernel_ms; /* device time of the path-tracing launch(es), HIP events on the launch stream */
+    uint32_t launches;
+} mi355pt_stats;
+
+/* ---------------- scene construction ---------------- */
+int mi355pt_scene_create(mi355pt_scene** out);             /* scene::create_scene!()                     scene.rs:266-285 */
+void mi355pt_scene_destroy(mi355pt_scene* s);
+/* rgb_to_spec::SRGB_DATA: [64 z_nodes][3][64][64][64][3] f32   rgb_to_spec/src/lib.rs:1-4, rgb_sigmoid_polynomial.rs:35-84 */
+int mi355pt_scene_set_rgb2spec(mi355pt_scene* s, const float* table, size_t n_floats);
+/* a preset spectrum baked to 470 1-nm entries        spectrum/src/presets.rs:75-231, densely_sampled_spectrum.rs:40-53 */
+int mi355pt_scene_add_lut470(mi355pt_scene* s, const float values[470], uint32_t* out_id);
+/* RgbTexture::load_srgb / NormalTexture::load (8-bit RGB, row-major, top row first)  texture/loader.rs:44-64 */
+int mi355pt_scene_add_tex_rgb8(mi355pt_scene* s, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t* out_id);
+/* Scene::load_obj -> TriangleMesh{positions,normals,uvs,tangents,indices}  geometry/impls/triangle_mesh.rs:130-242.
+ * uv may be NULL (no texcoords); tri_tangent (one vec3 per triangle) may be NULL only if uv is NULL. */
+int mi355pt_scene_add_mesh(mi355pt_scene* s, const float* pos, const float* nrm, const float* uv, const float* tri_tangent,
+                           const uint32_t* idx, uint32_t n_vert, uint32_t n_tri, uint32_t* out_geom);
+int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* desc, uint32_t* out_mat);
+/* Scene::create_primitive(CreatePrimitiveDesc::GeometryPrimitive{geometry_index, surface_material, transform})
+ * scene.rs:57-61, primitive/create_desc.rs:10-15.  Emissive materials make the instance an area light. */
+int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, const float local_to_world[16]);
+/* Scene::build(&camera): world->render translation, BVH build, light list; uploads to the current HIP device.
+ * scene.rs:64-76 */
+int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam);
+
+/* ---------------- rendering ---------------- */
+/* RendererImage::render::<S>() + Sensor::to_rgb: fills out_rgb (host, W*H*3, row-major, y down) with
+ * tone-mapped sRGB-encoded values in [0,1] exactly like RendererImage.pixels.  renderer.rs:101-134, sensor.rs:81-88 */
+int mi355pt_render(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, float* out_rgb,
+                   mi355pt_stats* stats /* NULL ok */);
+/* The same pixel loop with inputs and outputs resident in HBM: adds the *linear* per-pixel RGB sums of
+ * sample indices [sample_begin, sample_end) into d_accum (device, W*H*3 f32; Sensor.accumulated_rgb,
+ * sensor.rs:12-20,77).  Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  This is
+ * what the multi-GPU path reduces with RCCL before resolving. */
+int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p,
+                                uint32_t sample_begin, uint32_t sample_end, float* d_accum, void* hip_stream,
+                                mi355pt_stats* stats /* NULL ok; non-NULL synchronises the stream */);
+/* Sensor::to_rgb on device buffers: mean over spp, clip, Reinhard, sRGB OETF.  sensor.rs:81-88, tone_map.rs:20-28 */
+int mi355pt_film_resolve_device(const float* d_accum, uint32_t n_pixels, uint32_t spp, float* d_out_rgb, void* hip_stream);
+/* RendererImage::save quantisation `(p*255.0) as u8`  renderer.rs:137-148 (host helper) */
+int mi355pt_quantize_u8(const float* rgb, size_t n, uint8_t* out);
+
+/* ---------------- probes (parity tests; same device code as the render path) ---------------- */
+/* ZSobolSampler: for each query (x, y, sample_index) emit n_dims raw 32-bit Sobol outputs following the draw
+ * pattern string `pattern` of '1' (get_1d) and '2' (get_2d) characters.  z_sobol_sampler.rs:198-230 */
+int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t seed, const uint32_t* xys /* n*3 */,
+                        uint32_t n, const char* pattern, uint32_t* out_bits /* n * n_values(pattern) */);
+/* Scene::intersect for n rays (render space).  out_t < 0 means miss.  scene.rs:80-90 */
+int mi355pt_probe_intersect(const mi355pt_scene* s, const float* origins, const float* dirs, uint32_t n, float* out_t,
+                            uint32_t* out_instance, uint32_t* out_triangle, float* out_normal /* n*3 geometric, NULL ok */);
+/* Scene::intersect_p for n rays.  scene.rs:93-103 */
+int mi355pt_probe_occluded(const mi355pt_scene* s, const float* origins, const float* dirs, const float* t_max, uint32_t n,
+                           uint8_t* out_hit);
+/* BaseSrgbRenderer::render's per-sample result before the sensor: L[4], lambda[4], pdf[4] for n (x,y,sample) queries */
+int mi355pt_probe_radiance(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, const uint32_t* xys,
+                           uint32_t n, float* out_L, float* out_lambda, float* out_pdf);
+
+const char* mi355pt_last_error(void); /* thread-local message of the last failing call */
+const char* mi355pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PT_H */

@@ -1,0 +1,353 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// Restatement of scene/src/material/{common,edf}.rs, bsdf/{lambert,dielectric}.rs and
+// impls/{lambert,emissive,glass,plastic}_material.rs.
+#pragma once
+#include "o_scene.hpp"
+
+namespace oracle {
+
+constexpr float PI_F = 3.14159265358979323846f;
+
+enum BsdfSampleType : uint32_t { ST_DIFFUSE = 0, ST_SPEC_REFL = 1, ST_SPEC_TRANS = 2, ST_GLOSSY_REFL = 3, ST_GLOSSY_TRANS = 4 };
+
+struct MaterialSample {     // samples.rs:35-91
+    SS f = SS::zero(); V3 wi{0, 0, 1}; float pdf = 0.0f; uint32_t sample_type = ST_DIFFUSE; bool is_sampled = false;
+    bool is_specular() const { return sample_type == ST_SPEC_REFL || sample_type == ST_SPEC_TRANS; }
+    bool is_non_specular() const { return !is_specular(); }   // Diffuse | GlossyReflection | GlossyTransmission
+};
+struct BsdfSample { SS f; V3 wi; float pdf; uint32_t type; };
+
+// ---------------- material/common.rs ----------------
+static inline float cos2_theta(V3 w) { return w.z * w.z; }
+static inline float abs_cos_theta(V3 w) { return std::fabs(w.z); }
+static inline float tan2_theta(V3 w) {
+    float c2 = cos2_theta(w);
+    return c2 == 0.0f ? std::numeric_limits<float>::infinity() : (1.0f - c2) / c2;
+}
+static inline float cos_phi(V3 w) {
+    float st = std::sqrt(std::fmax(1.0f - cos2_theta(w), 0.0f));
+    return st == 0.0f ? 1.0f : clampf(w.x / st, -1.0f, 1.0f);
+}
+static inline float sin_phi(V3 w) {
+    float st = std::sqrt(std::fmax(1.0f - cos2_theta(w), 0.0f));
+    return st == 0.0f ? 0.0f : clampf(w.y / st, -1.0f, 1.0f);
+}
+static inline V3 reflect(V3 wo, V3 n) { return n * (2.0f * dot(wo, n)) - wo; }
+static inline bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.0f; }
+static inline V2 sample_uniform_disk_polar(V2 u) {
+    float r = std::sqrt(u.x), th = 2.0f * PI_F * u.y;
+    return V2{r * std::cos(th), r * std::sin(th)};
+}
+static inline SS fresnel_dielectric(float cos_theta_i, SS eta) {          // common.rs:87-105
+    cos_theta_i = clampf(cos_theta_i, 0.0f, 1.0f);
+    float sin2_i = 1.0f - cos_theta_i * cos_theta_i;
+    SS sin2_t = SS::constant(sin2_i) / (eta * eta);
+    SS cos_t = ss_sqrt(ss_clamp(SS::one() - sin2_t, 0.0f, 1.0f));
+    SS ci = SS::constant(cos_theta_i);
+    SS r_parl = (eta * ci - cos_t) / (eta * ci + cos_t);
+    SS r_perp = (ci - eta * cos_t) / (ci + eta * cos_t);
+    return (r_parl * r_parl + r_perp * r_perp) * 0.5f;
+}
+static inline bool refract(V3 wi, V3 n, float eta, V3* wt_out) {          // common.rs:117-139
+    float cos_i = dot(n, wi);
+    float sin2_i = std::fmax(1.0f - cos_i * cos_i, 0.0f);
+    float sin2_t = sin2_i / (eta * eta);
+    if (sin2_t >= 1.0f) return false;
+    float cos_t = std::sqrt(std::fmax(1.0f - sin2_t, 0.0f));
+    V3 wt = (-wi) / eta + n * (cos_i / eta - cos_t);
+    if (length_squared(wt) < 1e-12f) return false;
+    *wt_out = normalize(wt);
+    return true;
+}
+
+// ---------------- NormalizedLambertBsdf (bsdf/lambert.rs) ----------------
+static inline V3 sample_cosine_hemisphere(V2 uv) {
+    float r = std::sqrt(uv.x), th = 2.0f * PI_F * uv.y;
+    return V3{r * std::cos(th), r * std::sin(th), std::sqrt(1.0f - uv.x)};
+}
+static inline bool lambert_sample(SS albedo, V3 wo, V2 uv, BsdfSample* out) {
+    if (wo.z == 0.0f) return false;
+    V3 wi = sample_cosine_hemisphere(uv);
+    if (wo.z < 0.0f) wi = V3{wi.x, wi.y, -wi.z};
+    if (wi.z == 0.0f) return false;
+    if (signum(wo.z) != signum(wi.z)) return false;
+    out->f = albedo * std::fabs(wi.z) / PI_F;
+    out->wi = wi; out->pdf = std::fabs(wi.z) / PI_F; out->type = ST_DIFFUSE;
+    return true;
+}
+static inline SS lambert_evaluate(SS albedo, V3 wo, V3 wi) {
+    if (wo.z == 0.0f || wi.z == 0.0f) return SS::zero();
+    if (signum(wo.z) != signum(wi.z)) return SS::zero();
+    return albedo * std::fabs(wi.z) / PI_F;
+}
+static inline float lambert_pdf(V3 wo, V3 wi) {
+    if (wo.z == 0.0f || wi.z == 0.0f) return 0.0f;
+    if (signum(wo.z) != signum(wi.z)) return 0.0f;
+    return std::fabs(wi.z) / PI_F;
+}
+
+// ---------------- DielectricBsdf (bsdf/dielectric.rs) ----------------
+struct DielectricBsdf {
+    SS eta; bool entering, thin; float ax, ay;
+    DielectricBsdf(SS e, bool ent, bool th, float a_x, float a_y) : eta(e), entering(ent), thin(th), ax(a_x), ay(a_y) {
+        if (eta.v[0] == 0.0f) eta = SS::constant(1.0f);                   // :144-148
+    }
+    bool effectively_smooth() const { return std::fmax(ax, ay) < 1e-3f; }
+    float D(V3 wm) const {                                                // :29-41
+        float t2 = tan2_theta(wm);
+        if (!std::isfinite(t2)) return 0.0f;
+        float c4 = cos2_theta(wm) * cos2_theta(wm);
+        float cp = cos_phi(wm), sp = sin_phi(wm);
+        float e = t2 * ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay));
+        return 1.0f / (PI_F * ax * ay * c4 * ((1.0f + e) * (1.0f + e)));
+    }
+    float lambda(V3 w) const {                                            // :43-51
+        float t2 = tan2_theta(w);
+        if (std::isinf(t2)) return 0.0f;
+        float a = cos_phi(w) * ax, b = sin_phi(w) * ay;
+        float alpha2 = a * a + b * b;
+        return (std::sqrt(1.0f + alpha2 * t2) - 1.0f) / 2.0f;
+    }
+    float G1(V3 w) const { return 1.0f / (1.0f + lambda(w)); }
+    float G(V3 wo, V3 wi) const { return 1.0f / (1.0f + lambda(wo) + lambda(wi)); }
+    float Dw(V3 w, V3 wm) const {                                         // :65-75
+        float c = std::fabs(w.z);
+        if (c == 0.0f) return 0.0f;
+        return G1(w) / c * D(wm) * std::fabs(dot(w, wm));
+    }
+    V3 sample_wm(V3 w, V2 u) const {                                      // :77-112
+        V3 wh = normalize(V3{ax * w.x, ay * w.y, w.z});
+        if (wh.z < 0.0f) wh = -wh;
+        V3 t1 = wh.z < 0.99999f ? normalize(cross(V3{0, 0, 1}, wh)) : V3{1, 0, 0};
+        V3 t2 = cross(wh, t1);
+        V2 p = sample_uniform_disk_polar(u);
+        float h = std::sqrt(std::fmax(1.0f - p.x * p.x, 0.0f));
+        float lf = (1.0f + wh.z) / 2.0f;
+        float py = h * (1.0f - lf) + p.y * lf;
+        float pz = std::sqrt(std::fmax(1.0f - p.x * p.x - py * py, 0.0f));
+        V3 nh = t1 * p.x + t2 * py + wh * pz;
+        return normalize(V3{ax * nh.x, ay * nh.y, std::fmax(1e-6f, nh.z)});
+    }
+    SS eta_rel() const { return (thin || entering) ? eta : SS::one() / eta; }
+    static void thin_coeffs(float fr, float* r_out, float* t_out) {        // :367-378
+        float r = fr, t = 1.0f - r, r2 = r * r;
+        r = r2 > 1.0f ? 1.0f : r + (t * t * r) / (1.0f - r2);
+        *r_out = r; *t_out = t;
+    }
+    bool half_vector(V3 wo, V3 wi, float e, V3* wm_out) const {            // :184-215
+        float co = wo.z, ci = wi.z;
+        bool refl = ci * co > 0.0f;
+        float etap = !refl ? (co > 0.0f ? e : 1.0f / e) : 1.0f;
+        V3 wm = wi * etap + wo;
+        if (ci == 0.0f || co == 0.0f || length_squared(wm) == 0.0f) return false;
+        wm = normalize(wm);
+        if (wm.z < 0.0f) wm = -wm;
+        if (dot(wm, wi) * ci < 0.0f || dot(wm, wo) * co < 0.0f) return false;
+        *wm_out = wm; return true;
+    }
+    bool sample_specular(V3 wo, float uc, Wavelengths& wl, BsdfSample* out) const {   // :380-466
+        float wo_cos = wo.z;
+        V3 n = entering ? V3{0, 0, 1} : V3{0, 0, -1};
+        SS er = eta_rel();
+        float etap = er.v[0];
+        SS fr = fresnel_dielectric(std::fabs(wo_cos), er);
+        if (thin) {
+            float pr, pt; thin_coeffs(fr.average(), &pr, &pt);
+            if (uc < pr / (pr + pt)) {
+                if (std::fabs(wo_cos) < 1e-6f) return false;
+                *out = BsdfSample{fr, V3{-wo.x, -wo.y, wo.z}, pr / (pr + pt), ST_SPEC_REFL};
+                return true;
+            }
+            V3 wi{-wo.x, -wo.y, -wo.z};
+            if (wi.z == 0.0f) return false;
+            *out = BsdfSample{SS::one() - fr, wi, pt / (pr + pt), ST_SPEC_TRANS};
+            return true;
+        }
+        float pr = fr.average(), pt = 1.0f - pr;
+        if (uc < pr / (pr + pt)) {
+            if (std::fabs(wo_cos) < 1e-6f) return false;
+            *out = BsdfSample{fr, V3{-wo.x, -wo.y, wo.z}, pr / (pr + pt), ST_SPEC_REFL};
+            return true;
+        }
+        if (!eta.is_constant()) wl.terminate_secondary();
+        V3 wt;
+        if (!refract(wo, n, etap, &wt)) return false;
+        if (wt.z == 0.0f) return false;
+        SS f = (SS::one() - fr) / (etap * etap);
+        *out = BsdfSample{f, wt, pt / (pr + pt), ST_SPEC_TRANS};
+        return true;
+    }
+    bool sample_microfacet(V3 wo, V2 u, float uc, Wavelengths& wl, BsdfSample* out) const {   // :217-282
+        V3 wm = sample_wm(wo, u);
+        SS er = eta_rel();
+        float es = er.v[0];
+        SS fr = fresnel_dielectric(std::fabs(dot(wo, wm)), er);
+        float pr = fr.average(), pt = 1.0f - pr;
+        if (thin) {
+            float tr, tt; thin_coeffs(fr.average(), &tr, &tt);
+            if (uc < tr / (tr + tt)) return sample_mf_reflection(wo, wm, fr, tr / (tr + tt), out);
+            *out = BsdfSample{SS::one() - fr, V3{-wo.x, -wo.y, -wo.z}, tt / (tr + tt), ST_GLOSSY_TRANS};   // :346-365
+            return true;
+        }
+        if (uc < pr / (pr + pt)) return sample_mf_reflection(wo, wm, fr, pr / (pr + pt), out);
+        if (!eta.is_constant()) wl.terminate_secondary();
+        return sample_mf_transmission(wo, wm, SS::one() - fr, pt / (pr + pt), es, out);
+    }
+    bool sample_mf_reflection(V3 wo, V3 wm, SS fr, float prob, BsdfSample* out) const {       // :284-314
+        V3 wi = reflect(wo, wm);
+        if (!same_hemisphere(wo, wi)) return false;
+        float cd = std::fabs(dot(wo, wm));
+        if (cd < 1e-6f) return false;
+        float pdf = Dw(wo, wm) / (4.0f * cd) * prob;
+        float d = D(wm), g = G(wo, wi);
+        SS f = fr * d * g * abs_cos_theta(wi) / (4.0f * abs_cos_theta(wo));   // extra |cos wi| (Q8)
+        *out = BsdfSample{f, wi, pdf, ST_GLOSSY_REFL};
+        return true;
+    }
+    bool sample_mf_transmission(V3 wo, V3 wm, SS tr, float prob, float etap, BsdfSample* out) const {   // :316-344
+        V3 wmr = entering ? wm : -wm;
+        V3 wi;
+        if (!refract(wo, wmr, etap, &wi)) return false;
+        if (same_hemisphere(wo, wi) || std::fabs(wi.z) == 0.0f) return false;
+        float s = dot(wi, wm) + dot(wo, wm) / etap;
+        float denom = s * s;
+        float dwm_dwi = std::fabs(dot(wi, wm)) / denom;
+        float pdf = Dw(wo, wm) * dwm_dwi * prob;
+        float d = D(wm), g = G(wo, wi);
+        SS ft = tr * d * g * std::fabs(dot(wi, wm)) * std::fabs(dot(wo, wm)) / (denom * abs_cos_theta(wo) * etap * etap);
+        *out = BsdfSample{ft, wi, pdf, ST_GLOSSY_TRANS};
+        return true;
+    }
+    bool sample(V3 wo, V2 uv, float uc, Wavelengths& wl, BsdfSample* out) const {            // :164-182
+        if (wo.z == 0.0f) return false;
+        if (effectively_smooth()) return sample_specular(wo, uc, wl, out);
+        return sample_microfacet(wo, uv, uc, wl, out);
+    }
+    SS evaluate(V3 wo, V3 wi) const {                                       // :468-537
+        if (effectively_smooth()) return SS::zero();
+        SS er = eta_rel(); float es = er.v[0];
+        V3 wm;
+        if (!half_vector(wo, wi, es, &wm)) return SS::zero();
+        SS fr = fresnel_dielectric(std::fabs(dot(wo, wm)), er);
+        bool refl = wi.z * wo.z > 0.0f;
+        float d = D(wm), g = G(wo, wi);
+        if (refl) return fr * d * g / (4.0f * abs_cos_theta(wo));
+        float s = dot(wi, wm) + dot(wo, wm) / es;
+        float denom = s * s;
+        return (SS::one() - fr) * d * g * std::fabs(dot(wi, wm)) * std::fabs(dot(wo, wm)) / (denom * abs_cos_theta(wo) * es * es);
+    }
+    float pdf(V3 wo, V3 wi) const {                                         // :483-645
+        if (effectively_smooth()) return 0.0f;
+        SS er = eta_rel(); float es = er.v[0];
+        V3 wm;
+        if (!half_vector(wo, wi, es, &wm)) return 0.0f;
+        SS fr = fresnel_dielectric(std::fabs(dot(wo, wm)), er);
+        float pr = fr.average(), pt = 1.0f - pr;
+        bool refl = wi.z * wo.z > 0.0f;
+        if (refl) return Dw(wo, wm) / (4.0f * std::fabs(dot(wo, wm))) * pr / (pr + pt);
+        if (thin) return pt / (pr + pt);
+        float s = dot(wi, wm) + dot(wo, wm) / es;
+        float denom = s * s;
+        float dwm_dwi = std::fabs(dot(wi, wm)) / denom;
+        return Dw(wo, wm) * dwm_dwi * pt / (pr + pt);
+    }
+};
+
+// ---------------- material dispatch (BsdfSurfaceMaterial impls) ----------------
+struct ShadingPoint {   // SurfaceInteraction<VertexNormalTangent>
+    V3 normal;          // geometric normal in the vertex-normal tangent frame
+    V2 uv;
+};
+
+struct MaterialEval {
+    const Scene& scene; Counters* ctr;
+
+    M4 normal_map_transform(const Material& m, V2 uv) const {
+        V3 nm = m.normal_tex >= 0 ? sample_normal_map(scene.textures[m.normal_tex], m.normal_flip_y, uv) : V3{0, 0, 1};
+        return from_normal_map(nm);
+    }
+    SS eta_of(const Material& m, const Wavelengths& wl) const { return m.eta.sample(wl); }
+
+    MaterialSample sample(const Material& m, float uc, V2 uv, Wavelengths& wl, V3 wo, const ShadingPoint& sp) const;
+    SS evaluate(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const;
+    float pdf(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const;
+    // EmissiveMaterial::radiance (emissive_material.rs:48-60)
+    SS emissive_radiance(const Material& m, const Wavelengths& wl, V2 uv) const {
+        SS rad = scene.sample_spectrum_param(m.color, uv, wl, ctr);
+        return rad * m.intensity;
+    }
+};
+
+inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, Wavelengths& wl, V3 wo, const ShadingPoint& sp) const {
+    MaterialSample ms;
+    if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:42-97
+        SS albedo = scene.sample_spectrum_param(m.color, sp.uv, wl, ctr);
+        M4 tf = normal_map_transform(m, sp.uv);
+        M4 tf_inv = inverse(tf);
+        V3 wo_nm = transform_vector3(tf, wo);
+        BsdfSample bs;
+        if (!lambert_sample(albedo, wo_nm, uv, &bs)) return ms;
+        V3 wi_sh = transform_vector3(tf_inv, bs.wi);
+        if (signum(dot(sp.normal, wi_sh)) != signum(dot(sp.normal, wo))) return ms;
+        ms.f = bs.f; ms.wi = wi_sh; ms.pdf = bs.pdf; ms.sample_type = bs.type; ms.is_sampled = true;
+        return ms;
+    }
+    if (m.type == MAT_GLASS || m.type == MAT_PLASTIC) {                      // glass_material.rs:69-118, plastic_material.rs:88-139
+        SS eta = m.type == MAT_GLASS ? eta_of(m, wl) : SS::constant(m.eta.c[0]);
+        M4 tf = normal_map_transform(m, sp.uv);
+        M4 tf_inv = inverse(tf);
+        V3 wo_nm = transform_vector3(tf, wo);
+        bool entering = dot(sp.normal, wo) > 0.0f;
+        DielectricBsdf bsdf(eta, entering, m.thin, m.roughness, m.roughness);
+        BsdfSample bs;
+        if (!bsdf.sample(wo_nm, uv, uc, wl, &bs)) return ms;
+        if (m.type == MAT_PLASTIC && dot(bs.wi, wo_nm) < 0.0f) {
+            // reference quirk Q15: colour indexed with the *random* uv (plastic_material.rs:123-126)
+            bs.f = bs.f * scene.sample_spectrum_param(m.color, uv, wl, ctr);
+        }
+        ms.f = bs.f; ms.wi = transform_vector3(tf_inv, bs.wi); ms.pdf = bs.pdf; ms.sample_type = bs.type; ms.is_sampled = true;
+        return ms;
+    }
+    return ms;
+}
+
+inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const {
+    if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:99-131
+        SS albedo = scene.sample_spectrum_param(m.color, sp.uv, wl, ctr);
+        M4 tf = normal_map_transform(m, sp.uv);
+        V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
+        if (signum(dot(sp.normal, wi)) != signum(dot(sp.normal, wo))) return SS::zero();
+        return lambert_evaluate(albedo, wo_nm, wi_nm);
+    }
+    if (m.type == MAT_GLASS || m.type == MAT_PLASTIC) {
+        SS eta = m.type == MAT_GLASS ? eta_of(m, wl) : SS::constant(m.eta.c[0]);
+        M4 tf = normal_map_transform(m, sp.uv);
+        V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
+        bool entering = dot(sp.normal, wo) > 0.0f;
+        DielectricBsdf bsdf(eta, entering, m.thin, m.roughness, m.roughness);
+        SS f = bsdf.evaluate(wo_nm, wi_nm);
+        if (m.type == MAT_PLASTIC && dot(wi_nm, wo_nm) < 0.0f) f = f * scene.sample_spectrum_param(m.color, sp.uv, wl, ctr);
+        return f;
+    }
+    return SS::zero();
+}
+
+inline float MaterialEval::pdf(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const {
+    if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:133-159
+        M4 tf = normal_map_transform(m, sp.uv);
+        if (signum(dot(sp.normal, wi)) != signum(dot(sp.normal, wo))) return 0.0f;
+        V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
+        return lambert_pdf(wo_nm, wi_nm);
+    }
+    if (m.type == MAT_GLASS || m.type == MAT_PLASTIC) {
+        SS eta = m.type == MAT_GLASS ? eta_of(m, wl) : SS::constant(m.eta.c[0]);
+        M4 tf = normal_map_transform(m, sp.uv);
+        V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
+        bool entering = dot(sp.normal, wo) > 0.0f;
+        DielectricBsdf bsdf(eta, entering, m.thin, m.roughness, m.roughness);
+        return bsdf.pdf(wo_nm, wi_nm);
+    }
+    return 0.0f;
+}
+
+}  // namespace oracle

@@ -1,0 +1,263 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// Restatement of scene/src/{scene,samples,light_sampler}.rs, scene/src/primitive/{bvh,impls/
+// triangle_mesh,impls/emissive_triangle_mesh}.rs and scene/src/geometry/impls/triangle_mesh.rs.
+#pragma once
+#include <memory>
+#include <vector>
+#include "o_bvh.hpp"
+#include "o_spectrum.hpp"
+
+namespace oracle {
+
+// ---------------- parameters / materials (material/parameter.rs) ----------------
+enum SpectrumParamKind : uint32_t { SP_CONSTANT = 0, SP_TEXTURE_ALBEDO_SRGB = 1 };
+struct SpectrumParameter {
+    uint32_t kind = SP_CONSTANT;
+    Spectrum constant;
+    int texture = -1;
+};
+
+enum MaterialType : uint32_t { MAT_LAMBERT = 0, MAT_EMISSIVE = 1, MAT_GLASS = 2, MAT_PLASTIC = 3, MAT_CLEARCOAT = 4 };
+
+struct Material {
+    uint32_t type = MAT_LAMBERT;
+    SpectrumParameter color;       // Lambert albedo / Emissive radiance / Plastic colour / Clearcoat base colour
+    int normal_tex = -1;           // NormalParameter::Texture
+    bool normal_flip_y = false;
+    float intensity = 1.0f;        // Emissive FloatParameter::Constant
+    Spectrum eta;                  // Glass: LUT spectrum; Plastic: constant
+    bool thin = false;
+    float roughness = 0.0f;
+    // clearcoat (simple_pbr_clearcoat_material.rs): filled by the API when type == MAT_CLEARCOAT
+    float cc_metallic = 0, cc_base_ior = 1.5f, cc_ior = 1.5f, cc_roughness = 0, cc_thickness = 0;
+    SpectrumParameter cc_tint;
+    bool is_emissive() const { return type == MAT_EMISSIVE; }
+};
+
+// ---------------- geometry (geometry/impls/triangle_mesh.rs) ----------------
+struct GeomHit {            // geometry::Intersection
+    V3 position, normal, shading_normal, tangent; V2 uv; uint32_t index; float t_hit;
+};
+
+struct TriangleMesh {
+    std::vector<V3> positions, normals, tangents;   // tangents: one per triangle (or empty)
+    std::vector<V2> uvs;                            // per vertex (or empty)
+    std::vector<uint32_t> indices;
+    Bounds bounds;
+    Bvh bvh;
+
+    void tri_positions(uint32_t t, V3 ps[3]) const {
+        ps[0] = positions[indices[t * 3]]; ps[1] = positions[indices[t * 3 + 1]]; ps[2] = positions[indices[t * 3 + 2]];
+    }
+    Bounds tri_bounds(uint32_t t) const {             // :31-39
+        V3 ps[3]; tri_positions(t, ps);
+        return Bounds{vmin(vmin(ps[0], ps[1]), ps[2]), vmax(vmax(ps[0], ps[1]), ps[2])};
+    }
+    void build() {                                    // :244-251
+        bounds = Bounds{positions[0], positions[0]};
+        for (auto& p : positions) bounds = Bounds{vmin(bounds.mn, p), vmax(bounds.mx, p)};
+        uint32_t nt = (uint32_t)(indices.size() / 3);
+        bvh = Bvh::build(nt, [this](uint32_t t) { return tri_bounds(t); });
+    }
+    bool tri_intersect(uint32_t t, const Ray& ray, float t_max, float* t_out, GeomHit* out) const {   // :41-109
+        V3 ps[3]; tri_positions(t, ps);
+        TriHit h;
+        if (!intersect_triangle(ray, t_max, ps, &h)) return false;
+        V3 n0 = normals[indices[t * 3]], n1 = normals[indices[t * 3 + 1]], n2 = normals[indices[t * 3 + 2]];
+        V3 sn = normalize(n0 * h.b[0] + n1 * h.b[1] + n2 * h.b[2]);           // normal.rs:68-78
+        V2 uv{0, 0};
+        if (!uvs.empty()) {
+            V2 u0 = uvs[indices[t * 3]], u1 = uvs[indices[t * 3 + 1]], u2 = uvs[indices[t * 3 + 2]];
+            uv = V2{u0.x * h.b[0] + u1.x * h.b[1] + u2.x * h.b[2], u0.y * h.b[0] + u1.y * h.b[1] + u2.y * h.b[2]};
+        }
+        V3 tangent = tangents.empty() ? generate_tangent(sn) : orthogonalize_vector(sn, tangents[t]);
+        *t_out = h.t;
+        *out = GeomHit{h.p, h.n, sn, tangent, uv, t, h.t};
+        return true;
+    }
+    bool tri_intersect_p(uint32_t t, const Ray& ray, float t_max) const {     // :111-126
+        V3 ps[3]; tri_positions(t, ps);
+        return intersect_triangle(ray, t_max, ps, nullptr);
+    }
+};
+
+// ---------------- SurfaceInteraction / Intersection (samples.rs, primitive/bvh.rs) ----------------
+struct SurfaceInteraction {
+    V3 position, normal, shading_normal, tangent; V2 uv; int material;
+};
+static inline SurfaceInteraction transform_interaction(const M4& m, const SurfaceInteraction& s) {   // samples.rs:130-143
+    return SurfaceInteraction{transform_point3(m, s.position), transform_normal(m, s.normal),
+                              transform_normal(m, s.shading_normal), transform_vector3(m, s.tangent), s.uv, s.material};
+}
+struct Intersection {
+    float t_hit; V3 wo; int primitive; uint32_t triangle; SurfaceInteraction interaction;
+};
+
+// ---------------- primitives (primitive/impls/{triangle_mesh,emissive_triangle_mesh}.rs) ----------------
+struct Primitive {
+    int geometry = -1;
+    int material = -1;
+    M4 local_to_world = M4::identity();
+    M4 local_to_render = M4::identity();
+    M4 render_to_local = M4::identity();   // used only by fast mode (hoisted inverse)
+    bool is_light = false;
+    std::vector<float> area_list, area_table;
+    float area_sum = 0.0f;
+};
+
+struct Counters {
+    TraversalCounters closest_tlas, closest_blas, any_tlas, any_blas;
+    uint64_t closest_rays = 0, shadow_rays = 0, closest_hits = 0, bounces = 0, samples = 0, sampler_draws = 0;
+    uint64_t spectrum_evals = 0, textured_lookups = 0;
+    void add(const Counters& o) {
+        auto a = [](TraversalCounters& x, const TraversalCounters& y) { x.nodes += y.nodes; x.items += y.items; };
+        a(closest_tlas, o.closest_tlas); a(closest_blas, o.closest_blas); a(any_tlas, o.any_tlas); a(any_blas, o.any_blas);
+        closest_rays += o.closest_rays; shadow_rays += o.shadow_rays; closest_hits += o.closest_hits;
+        bounces += o.bounces; samples += o.samples; sampler_draws += o.sampler_draws;
+        spectrum_evals += o.spectrum_evals; textured_lookups += o.textured_lookups;
+    }
+};
+
+struct Scene {
+    Rgb2SpecTable table;
+    std::vector<std::vector<float>> luts;
+    std::vector<TextureRgb8> textures;
+    std::vector<std::unique_ptr<TriangleMesh>> geometries;
+    std::vector<Material> materials;
+    std::vector<Primitive> primitives;
+    std::vector<int> light_list;                  // LightSamplerFactory::light_list
+    Bvh tlas;
+    bool faithful = true;                         // see o_bvh.hpp
+    bool built = false;
+
+    // EmissiveTriangleMesh::new (emissive_triangle_mesh.rs:28-68)
+    void init_light(Primitive& p) {
+        const TriangleMesh& m = *geometries[p.geometry];
+        p.area_list.clear(); p.area_table.clear();
+        for (size_t t = 0; t < m.indices.size() / 3; ++t) {
+            V3 p0 = transform_point3(p.local_to_world, m.positions[m.indices[t * 3]]);
+            V3 p1 = transform_point3(p.local_to_world, m.positions[m.indices[t * 3 + 1]]);
+            V3 p2 = transform_point3(p.local_to_world, m.positions[m.indices[t * 3 + 2]]);
+            V3 e0 = p0 - p1, e1 = p0 - p2;                       // p1.vector_to(p0), p2.vector_to(p0)
+            p.area_list.push_back(length(cross(e0, e1)) * 0.5f);
+        }
+        float s = 0.0f;
+        for (float a : p.area_list) { s += a; p.area_table.push_back(s); }
+        p.area_sum = s;
+        for (float& a : p.area_table) a /= s;
+    }
+
+    // Scene::build (scene.rs:64-76): Render = World - camera position
+    void build(V3 cam_pos) {
+        M4 world_to_render = M4::from_translation(-cam_pos);     // camera.rs:84-86
+        light_list.clear();
+        for (size_t i = 0; i < primitives.size(); ++i) {
+            Primitive& p = primitives[i];
+            p.local_to_render = world_to_render * p.local_to_world;
+            p.render_to_local = inverse(p.local_to_render);
+            p.is_light = materials[p.material].is_emissive();
+            if (p.is_light) { init_light(p); light_list.push_back((int)i); }
+        }
+        for (auto& g : geometries) if (g->bvh.nodes.empty()) g->build();
+        tlas = Bvh::build((uint32_t)primitives.size(), [this](uint32_t i) {
+            return transform_bounds(primitives[i].local_to_render, geometries[primitives[i].geometry]->bounds);
+        });
+        built = true;
+    }
+
+    // primitive/impls/triangle_mesh.rs:89-119 — ray to local (Mat4 inverse per call), hit back to render.
+    bool primitive_intersect(uint32_t pi, const Ray& ray, float t_max, float* t_out, Intersection* out, Counters* c) const {
+        const Primitive& p = primitives[pi];
+        const TriangleMesh& g = *geometries[p.geometry];
+        M4 inv = faithful ? inverse(p.local_to_render) : p.render_to_local;
+        Ray lr = transform_ray(inv, ray);
+        GeomHit gh;
+        auto item = [&](uint32_t t, const Ray& r, float tm, float* to, GeomHit* ho) { return g.tri_intersect(t, r, tm, to, ho); };
+        if (!g.bvh.intersect<GeomHit>(lr, t_max, item, !faithful, &gh, c ? &c->closest_blas : nullptr)) return false;
+        SurfaceInteraction si{gh.position, gh.normal, gh.shading_normal, gh.tangent, gh.uv, p.material};
+        out->t_hit = gh.t_hit;
+        out->wo = transform_vector3(p.local_to_render, -lr.d);
+        out->primitive = (int)pi;
+        out->triangle = gh.index;
+        out->interaction = transform_interaction(p.local_to_render, si);
+        *t_out = gh.t_hit;
+        return true;
+    }
+    bool primitive_intersect_p(uint32_t pi, const Ray& ray, float t_max, Counters* c) const {
+        const Primitive& p = primitives[pi];
+        const TriangleMesh& g = *geometries[p.geometry];
+        M4 inv = faithful ? inverse(p.local_to_render) : p.render_to_local;
+        Ray lr = transform_ray(inv, ray);
+        auto item = [&](uint32_t t, const Ray& r, float tm) { return g.tri_intersect_p(t, r, tm); };
+        return g.bvh.intersect_p(lr, t_max, item, c ? &c->any_blas : nullptr);
+    }
+    // Scene::intersect / intersect_p (scene.rs:80-103)
+    bool intersect(const Ray& ray, float t_max, Intersection* out, Counters* c) const {
+        if (c) c->closest_rays++;
+        auto item = [&](uint32_t pi, const Ray& r, float tm, float* to, Intersection* ho) {
+            return primitive_intersect(pi, r, tm, to, ho, c);
+        };
+        bool hit = tlas.intersect<Intersection>(ray, t_max, item, !faithful, out, c ? &c->closest_tlas : nullptr);
+        if (hit && c) c->closest_hits++;
+        return hit;
+    }
+    bool intersect_p(const Ray& ray, float t_max, Counters* c) const {
+        if (c) c->shadow_rays++;
+        auto item = [&](uint32_t pi, const Ray& r, float tm) { return primitive_intersect_p(pi, r, tm, c); };
+        return tlas.intersect_p(ray, t_max, item, c ? &c->any_tlas : nullptr);
+    }
+
+    // ---- spectrum parameter evaluation (parameter.rs:38-47, rgb_texture.rs:48-66) ----
+    SS sample_spectrum_param(const SpectrumParameter& sp, V2 uv, const Wavelengths& w, Counters* c) const {
+        if (c) c->spectrum_evals++;
+        if (sp.kind == SP_CONSTANT) return sp.constant.sample(w);
+        if (c) c->textured_lookups++;
+        float rgb[3];
+        bilinear_sample_rgb(textures[sp.texture], uv, rgb);
+        Spectrum s; s.kind = SPEC_SIGMOID;
+        table.get_srgb_encoded(rgb, s.c);
+        return s.sample(w);
+    }
+
+    // ---- lights ----
+    // EmissiveMaterial::average_intensity * area_sum (emissive_material.rs:63-79, emissive_triangle_mesh.rs:166-173)
+    SS light_phi(int prim, const Wavelengths& w) const {
+        const Primitive& p = primitives[prim];
+        const Material& m = materials[p.material];
+        SS rad = sample_spectrum_param(m.color, V2{0.5f, 0.5f}, w, nullptr);
+        return (rad * m.intensity) * p.area_sum;
+    }
+};
+
+// LightSampler (light_sampler.rs:26-62,190-220) — rebuilt per call, as the reference does.
+struct LightSampler {
+    const Scene* scene;
+    std::vector<float> weights, table;
+    float weight_sum = 0.0f;
+    LightSampler(const Scene& s, const Wavelengths& w) : scene(&s) {
+        for (int pi : s.light_list) {
+            float wt = s.light_phi(pi, w).average();
+            weight_sum += wt;
+            weights.push_back(wt);
+        }
+        table.assign(weights.size(), 0.0f);
+        float cum = 0.0f;
+        for (size_t i = 0; i < table.size(); ++i) { cum += weights[i]; table[i] = cum / weight_sum; }
+    }
+    bool sample_light(float u, int* prim, float* prob) const {
+        if (table.empty() || weight_sum == 0.0f) return false;
+        for (size_t i = 0; i < table.size(); ++i)
+            if (u < table[i]) { *prim = scene->light_list[i]; *prob = weights[i] / weight_sum; return true; }
+        size_t l = table.size() - 1;
+        *prim = scene->light_list[l]; *prob = weights[l] / weight_sum;
+        return true;
+    }
+    float probability(int prim) const {
+        if (table.empty() || weight_sum == 0.0f) return 0.0f;
+        for (size_t i = 0; i < scene->light_list.size(); ++i)
+            if (scene->light_list[i] == prim) return weights[i] / weight_sum;
+        return 0.0f;
+    }
+};
+
+}  // namespace oracle

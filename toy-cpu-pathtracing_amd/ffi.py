@@ -1,0 +1,273 @@
+"""ctypes view of include/mi355pt.h and a thin object wrapper over the C ABI.
+
+This is plumbing for tests / bench / smoke: the product is libmi355pt.so (hand-written HIP for
+gfx950 behind the C ABI).  There is no CPU fallback: if the shared library is missing this module
+raises, and every compute entry point fails loudly when no gfx950 device is present.
+
+`Backend` is prefix-agnostic so that the *oracle's* C entry points (oracle/libptoracle.so, prefix
+`ptoracle_`, test infrastructure only) can be driven with the very same scene description — the
+oracle binding itself lives in oracle/ptoracle.py, not here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "csrc", "libmi355pt.so")
+
+NONE = 0xFFFFFFFF
+SPEC_CONSTANT, SPEC_RGB_ALBEDO_SRGB, SPEC_LUT470, SPEC_TEXTURE_ALBEDO_SRGB, SPEC_SIGMOID = 0, 1, 2, 3, 4
+MAT_LAMBERT, MAT_EMISSIVE, MAT_GLASS, MAT_PLASTIC, MAT_CLEARCOAT = 0, 1, 2, 3, 4
+STRATEGY = {"pt": 0, "nee": 1, "mis": 2}
+SAMPLER = {"random": 0, "sobol": 1}
+
+
+class Spectrum(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("id", C.c_uint32), ("c", C.c_float * 3)]
+
+    @staticmethod
+    def constant(v):
+        return Spectrum(SPEC_CONSTANT, 0, (C.c_float * 3)(v, 0, 0))
+
+    @staticmethod
+    def rgb_albedo_srgb(r, g, b):
+        return Spectrum(SPEC_RGB_ALBEDO_SRGB, 0, (C.c_float * 3)(r, g, b))
+
+    @staticmethod
+    def lut(i):
+        return Spectrum(SPEC_LUT470, i, (C.c_float * 3)(0, 0, 0))
+
+    @staticmethod
+    def texture_albedo_srgb(i):
+        return Spectrum(SPEC_TEXTURE_ALBEDO_SRGB, i, (C.c_float * 3)(0, 0, 0))
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("color", Spectrum), ("normal_tex", C.c_uint32), ("normal_flip_y", C.c_uint32),
+                ("intensity", C.c_float), ("eta", Spectrum), ("thin", C.c_uint32), ("roughness", C.c_float),
+                ("metallic", C.c_float), ("ior", C.c_float), ("clearcoat_ior", C.c_float), ("clearcoat_roughness", C.c_float),
+                ("clearcoat_thickness", C.c_float), ("clearcoat_tint", Spectrum)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("direction", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov_deg", C.c_float), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("spp", C.c_uint32), ("seed", C.c_uint32), ("max_depth", C.c_uint32), ("strategy", C.c_uint32),
+                ("sampler", C.c_uint32), ("exposure", C.c_float), ("shard_index", C.c_uint32),
+                ("shard_count", C.c_uint32), ("collect_stats", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest",
+                                          "nodes_shadow", "tris_shadow", "closest_hits", "bounces", "spectrum_evals",
+                                          "textured_lookups")] + [("kernel_ms", C.c_double), ("launches", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def make_camera(position, direction, up, width, height, fov_deg=45.0):
+    return Camera((C.c_float * 3)(*position), (C.c_float * 3)(*direction), (C.c_float * 3)(*up), fov_deg, width, height)
+
+
+def make_params(spp, strategy="mis", sampler="sobol", seed=0, max_depth=16, exposure=1.0, shard_index=0, shard_count=1,
+                collect_stats=0):
+    return Params(spp, seed, max_depth, STRATEGY[strategy], SAMPLER[sampler], exposure, shard_index, shard_count, collect_stats)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty)) if a is not None else None
+
+
+# every symbol include/mi355pt.h declares (tests/test_abi.py checks the built library exports all of them)
+ABI_SYMBOLS = [
+    "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
+    "scene_add_material", "scene_add_instance", "scene_build", "render", "render_accum_device", "film_resolve_device",
+    "quantize_u8", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "last_error", "version",
+]
+
+
+class Backend:
+    """Prefix-agnostic binding of the scene-construction / probe subset shared by product and oracle."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.prefix = lib, prefix
+        f = self.fn
+        f("scene_create").argtypes = [C.POINTER(C.c_void_p)]
+        f("scene_destroy").argtypes = [C.c_void_p]; f("scene_destroy").restype = None
+        f("scene_set_rgb2spec").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]
+        f("scene_add_lut470").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        f("scene_add_tex_rgb8").argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        f("scene_add_mesh").argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4 + [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        f("scene_add_material").argtypes = [C.c_void_p, C.POINTER(MaterialDesc), C.POINTER(C.c_uint32)]
+        f("scene_add_instance").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        f("scene_build").argtypes = [C.c_void_p, C.POINTER(Camera)]
+        f("probe_sobol").argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32)]
+        f("probe_intersect").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        f("probe_occluded").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32,
+                                        C.POINTER(C.c_uint8)]
+        f("probe_radiance").argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.POINTER(C.c_uint32), C.c_uint32,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        f("quantize_u8").argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint8)]
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = ""
+            if self.prefix == "mi355pt_":
+                self.lib.mi355pt_last_error.restype = C.c_char_p
+                msg = (self.lib.mi355pt_last_error() or b"").decode()
+            raise RuntimeError(f"{self.prefix}{what} failed with code {rc}: {msg}")
+
+    def new_scene(self):
+        return SceneHandle(self)
+
+    def probe_sobol(self, width, height, spp, seed, xys, pattern):
+        xys = np.ascontiguousarray(xys, dtype=np.uint32).reshape(-1, 3)
+        per = sum(2 if ch == "2" else 1 for ch in pattern)
+        out = np.zeros((xys.shape[0], per), dtype=np.uint32)
+        self.check(self.fn("probe_sobol")(width, height, spp, seed, _ptr(xys, C.c_uint32), xys.shape[0], pattern.encode(),
+                                           _ptr(out, C.c_uint32)), "probe_sobol")
+        return out
+
+    def quantize_u8(self, rgb):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        out = np.zeros(rgb.shape, dtype=np.uint8)
+        self.check(self.fn("quantize_u8")(_ptr(rgb, C.c_float), rgb.size, _ptr(out, C.c_uint8)), "quantize_u8")
+        return out
+
+
+class SceneHandle:
+    """Owns one opaque scene; mirrors scene::Scene's construction API (scene/src/scene.rs:43-76)."""
+
+    def __init__(self, backend):
+        self.b = backend
+        self.h = C.c_void_p()
+        backend.check(backend.fn("scene_create")(C.byref(self.h)), "scene_create")
+        self.keep = []
+
+    def close(self):
+        if self.h:
+            self.b.fn("scene_destroy")(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_rgb2spec(self, table):
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        self.b.check(self.b.fn("scene_set_rgb2spec")(self.h, _ptr(table, C.c_float), table.size), "scene_set_rgb2spec")
+
+    def add_lut470(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        assert v.size == 470
+        out = C.c_uint32()
+        self.b.check(self.b.fn("scene_add_lut470")(self.h, _ptr(v, C.c_float), C.byref(out)), "scene_add_lut470")
+        return out.value
+
+    def add_tex_rgb8(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w, c = img.shape
+        assert c == 3
+        out = C.c_uint32()
+        self.b.check(self.b.fn("scene_add_tex_rgb8")(self.h, _ptr(img, C.c_uint8), w, h, C.byref(out)), "scene_add_tex_rgb8")
+        return out.value
+
+    def add_mesh(self, mesh):
+        pos = np.ascontiguousarray(mesh["pos"], dtype=np.float32)
+        nrm = np.ascontiguousarray(mesh["nrm"], dtype=np.float32)
+        uv = None if mesh.get("uv") is None else np.ascontiguousarray(mesh["uv"], dtype=np.float32)
+        tan = None if mesh.get("tangent") is None else np.ascontiguousarray(mesh["tangent"], dtype=np.float32)
+        idx = np.ascontiguousarray(mesh["idx"], dtype=np.uint32).reshape(-1)
+        out = C.c_uint32()
+        self.b.check(self.b.fn("scene_add_mesh")(self.h, _ptr(pos, C.c_float), _ptr(nrm, C.c_float), _ptr(uv, C.c_float),
+                                                  _ptr(tan, C.c_float), _ptr(idx, C.c_uint32), pos.shape[0], idx.size // 3,
+                                                  C.byref(out)), "scene_add_mesh")
+        return out.value
+
+    def add_material(self, desc):
+        out = C.c_uint32()
+        self.b.check(self.b.fn("scene_add_material")(self.h, C.byref(desc), C.byref(out)), "scene_add_material")
+        return out.value
+
+    def add_instance(self, geom, mat, local_to_world=None):
+        m = np.eye(4, dtype=np.float32) if local_to_world is None else np.asarray(local_to_world, dtype=np.float32)
+        cols = np.ascontiguousarray(m.T.reshape(-1))   # column-major
+        self.b.check(self.b.fn("scene_add_instance")(self.h, geom, mat, _ptr(cols, C.c_float)), "scene_add_instance")
+
+    def build(self, cam):
+        self.b.check(self.b.fn("scene_build")(self.h, C.byref(cam)), "scene_build")
+
+    # ---- probes ----
+    def probe_intersect(self, origins, dirs):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.zeros(n, np.float32); inst = np.zeros(n, np.uint32); tri = np.zeros(n, np.uint32); nrm = np.zeros((n, 3), np.float32)
+        self.b.check(self.b.fn("probe_intersect")(self.h, _ptr(o, C.c_float), _ptr(d, C.c_float), n, _ptr(t, C.c_float),
+                                                   _ptr(inst, C.c_uint32), _ptr(tri, C.c_uint32), _ptr(nrm, C.c_float)), "probe_intersect")
+        return t, inst, tri, nrm
+
+    def probe_occluded(self, origins, dirs, t_max):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        tm = np.ascontiguousarray(t_max, dtype=np.float32).reshape(-1)
+        out = np.zeros(o.shape[0], np.uint8)
+        self.b.check(self.b.fn("probe_occluded")(self.h, _ptr(o, C.c_float), _ptr(d, C.c_float), _ptr(tm, C.c_float), o.shape[0],
+                                                  _ptr(out, C.c_uint8)), "probe_occluded")
+        return out
+
+    def probe_radiance(self, cam, params, xys):
+        xys = np.ascontiguousarray(xys, dtype=np.uint32).reshape(-1, 3)
+        n = xys.shape[0]
+        L = np.zeros((n, 4), np.float32); lam = np.zeros((n, 4), np.float32); pdf = np.zeros((n, 4), np.float32)
+        self.b.check(self.b.fn("probe_radiance")(self.h, C.byref(cam), C.byref(params), _ptr(xys, C.c_uint32), n, _ptr(L, C.c_float),
+                                                  _ptr(lam, C.c_float), _ptr(pdf, C.c_float)), "probe_radiance")
+        return L, lam, pdf
+
+
+class Product(Backend):
+    """libmi355pt.so — the HIP product.  Raises if the extension has not been built."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+        lib = C.CDLL(path)
+        super().__init__(lib, "mi355pt_")
+        lib.mi355pt_version.restype = C.c_char_p
+        lib.mi355pt_last_error.restype = C.c_char_p
+        lib.mi355pt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(Stats)]
+        lib.mi355pt_render_accum_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32,
+                                                    C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        lib.mi355pt_film_resolve_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+
+    def version(self):
+        return self.lib.mi355pt_version().decode()
+
+    def render(self, scene, cam, params, want_stats=False):
+        """RendererImage::render -> (H, W, 3) float32 tone-mapped sRGB in [0,1] (renderer.rs:120-134)."""
+        out = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        st = Stats()
+        self.check(self.lib.mi355pt_render(scene.h, C.byref(cam), C.byref(params), _ptr(out, C.c_float), C.byref(st)), "render")
+        return (out, st) if want_stats else out
+
+    def render_accum_device(self, scene, cam, params, s_begin, s_end, d_accum_ptr, stream=None, stats=None):
+        self.check(self.lib.mi355pt_render_accum_device(scene.h, C.byref(cam), C.byref(params), s_begin, s_end, C.c_void_p(d_accum_ptr),
+                                                        C.c_void_p(stream or 0), C.byref(stats) if stats is not None else None),
+                   "render_accum_device")
+
+    def film_resolve_device(self, d_accum_ptr, n_pixels, spp, d_out_ptr, stream=None):
+        self.check(self.lib.mi355pt_film_resolve_device(C.c_void_p(d_accum_ptr), n_pixels, spp, C.c_void_p(d_out_ptr),
+                                                        C.c_void_p(stream or 0)), "film_resolve_device")

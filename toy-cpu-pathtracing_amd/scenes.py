@@ -1,0 +1,136 @@
+"""Scene authoring: the four BASELINE configs' scenes, mirroring renderer/src/scene/scene_{3,8,10,17}.rs
+call for call against the C ABI (works with any ffi.Backend).  Assets are the synthetic stand-ins of
+assets.py (the reference's OBJ/PNG files are LFS stubs)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+
+from . import assets
+from .ffi import (HERE, MAT_CLEARCOAT, MAT_EMISSIVE, MAT_GLASS, MAT_LAMBERT, MAT_PLASTIC, NONE, MaterialDesc, Spectrum,
+                  make_camera)
+
+DATA = os.path.join(HERE, "data")
+
+
+def presets():
+    """{name: 470 x f32} baked by tools/bake_presets.py from spectrum/src/presets.rs."""
+    names = json.load(open(os.path.join(DATA, "presets470.json")))["names"]
+    d = np.fromfile(os.path.join(DATA, "presets470.bin"), dtype="<f4").reshape(len(names), 470)
+    return {n: d[i] for i, n in enumerate(names)}
+
+
+def cmf_xyz():
+    p = presets()
+    return np.ascontiguousarray(np.stack([p["cie_x"], p["cie_y"], p["cie_z"]]), dtype=np.float32)
+
+
+def srgb_table():
+    """The sRGB coefficient table (rgb_to_spec/tables/srgb_table.bin layout), generated on demand."""
+    path = os.path.join(DATA, "srgb_table.bin")
+    if not os.path.exists(path):
+        root = os.path.dirname(HERE)
+        exe = os.path.join(root, "tools", "rgb2spec_fit")
+        if not os.path.exists(exe):
+            subprocess.check_call(["g++", "-O3", "-std=c++17", "-pthread", "-o", exe, os.path.join(root, "tools", "rgb2spec_fit.cpp")])
+        names = json.load(open(os.path.join(DATA, "presets470.json")))["names"]
+        ix = [str(names.index(k)) for k in ("cie_x", "cie_y", "cie_z", "cie_illum_d6500")]
+        subprocess.check_call([exe, os.path.join(DATA, "presets470.bin"), *ix, path, str(min(16, os.cpu_count() or 1))])
+    t = np.fromfile(path, dtype="<f4")
+    assert t.size == 64 + 3 * 64 ** 3 * 3
+    return t
+
+
+_ASSET_CACHE = {}
+
+
+def _asset(name):
+    if name not in _ASSET_CACHE:
+        if name == "room":
+            _ASSET_CACHE[name] = {k: assets.load_obj_semantics(v) for k, v in assets.cornell_room().items()}
+        elif name == "bunny":
+            _ASSET_CACHE[name] = assets.load_obj_semantics(assets.bunny_class())
+        elif name == "dragon":
+            _ASSET_CACHE[name] = assets.load_obj_semantics(assets.dragon_class())
+        elif name.startswith("tex"):
+            _ASSET_CACHE[name] = assets.bunny_textures(int(name[3:]))
+    return _ASSET_CACHE[name]
+
+
+def lambert(color, normal_tex=NONE):
+    d = MaterialDesc(); d.type = MAT_LAMBERT; d.color = color; d.normal_tex = normal_tex; d.normal_flip_y = 0
+    return d
+
+
+def _room(scene, p, with_box=True):
+    """box/hidari/migi/yuka/oku/tenjou/light — scene_3.rs:33-107 (identical in scenes 8, 10, 17)."""
+    room = _asset("room")
+    grey = Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8)
+    order = [("box", grey), ("hidari", Spectrum.rgb_albedo_srgb(0.9, 0.0, 0.0)), ("migi", Spectrum.rgb_albedo_srgb(0.0, 0.9, 0.0)),
+             ("yuka", grey), ("oku", grey), ("tenjou", grey)]
+    for name, col in order:
+        if name == "box" and not with_box:
+            continue
+        g = scene.add_mesh(room[name])
+        scene.add_instance(g, scene.add_material(lambert(col)))
+    d65 = scene.add_lut470(p["cie_illum_d6500"])
+    em = MaterialDesc(); em.type = MAT_EMISSIVE; em.color = Spectrum.lut(d65); em.intensity = 10.0; em.normal_tex = NONE
+    g = scene.add_mesh(room["light"])
+    scene.add_instance(g, scene.add_material(em))
+
+
+def _mat4_trs_scene17():
+    """Transform::identity().rotate(Quat::from_euler(XYZ, 0, 120deg, 0)).scale(2.5).translate(0,0,0.5)
+    = T * S * R  (scene_17.rs:61-69, transform.rs:128-145), float32."""
+    a = np.float32(np.deg2rad(np.float32(120.0)))
+    c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+    R = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], dtype=np.float32)
+    S = np.diag(np.array([2.5, 2.5, 2.5, 1], dtype=np.float32))
+    T = np.eye(4, dtype=np.float32); T[2, 3] = 0.5
+    return (T @ (S @ R)).astype(np.float32)
+
+
+def load_scene(scene, scene_id, width, height, tex_size=1024):
+    """load_scene_N(&mut scene, &mut camera) + scene.build(&camera) (main.rs:70-106).  Returns the camera."""
+    p = presets()
+    scene.set_rgb2spec(srgb_table())
+    if scene_id == 3:      # scene_3.rs:13-31: textured + normal-mapped Lambert hero
+        g = scene.add_mesh(_asset("bunny"))
+        albedo, normal = _asset(f"tex{tex_size}")
+        t_alb = scene.add_tex_rgb8(albedo)
+        t_nrm = scene.add_tex_rgb8(normal)
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.texture_albedo_srgb(t_alb), t_nrm)))
+        _room(scene, p)
+        cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 0:    # scene_0.rs: constant-colour Lambert hero (used by small tests)
+        g = scene.add_mesh(_asset("bunny"))
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        _room(scene, p)
+        cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 8:    # scene_8.rs:17-27: SF11 glass hero
+        g = scene.add_mesh(_asset("bunny"))
+        d = MaterialDesc(); d.type = MAT_GLASS; d.eta = Spectrum.lut(scene.add_lut470(p["glass_sf11_eta"]))
+        d.normal_tex = NONE; d.thin = 0; d.roughness = 0.0; d.color = Spectrum.constant(1.0)
+        scene.add_instance(g, scene.add_material(d))
+        _room(scene, p)
+        cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 10:   # scene_10.rs:17-30: smooth thin-film plastic eta 1.8
+        g = scene.add_mesh(_asset("bunny"))
+        d = MaterialDesc(); d.type = MAT_PLASTIC; d.eta = Spectrum.constant(1.8); d.color = Spectrum.constant(1.0)
+        d.normal_tex = NONE; d.thin = 1; d.roughness = 0.0
+        scene.add_instance(g, scene.add_material(d))
+        _room(scene, p)
+        cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 17:   # scene_17.rs:20-70: rough clearcoat over rough metal
+        g = scene.add_mesh(_asset("dragon"))
+        d = MaterialDesc(); d.type = MAT_CLEARCOAT; d.color = Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8)
+        d.metallic = 1.0; d.roughness = 0.7; d.normal_tex = NONE; d.ior = 1.5; d.clearcoat_ior = 1.5
+        d.clearcoat_roughness = 0.75; d.clearcoat_tint = Spectrum.rgb_albedo_srgb(0.7, 0.8, 1.0); d.clearcoat_thickness = 0.8
+        scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
+        _room(scene, p)
+        cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    else:
+        raise ValueError(f"scene {scene_id} is outside the hot-path scope (SURVEY.md §8)")
+    scene.build(cam)
+    return cam
