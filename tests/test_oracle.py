@@ -1,0 +1,143 @@
+"""CPU tests of the oracle (oracle/): pinned against what the reference's own tree holds for this path.
+
+The reference has no unit tests and its golden PNGs are LFS stubs, so the pins are:
+  * the Sobol generator matrices (first 2 x 52 words of renderer/src/sampler/sobol_matrices.rs:7, committed as
+    data in tests/golden/sobol_matrices_dim01.json),
+  * structural properties the reference's sampler must have (digit-permutation bijectivity, the documented
+    odd-log2 duplicate-pair quirk and u32 Morton aliasing),
+  * the reference's estimator-consistency criterion PT == NEE == MIS <= 0.013 after a 3x3 median
+    (renderer/tests/renderer_consistency_test.rs:7,319-353) at a reduced size,
+  * the rgb_to_spec round-trip method of rgb_to_spec/tests/test.rs:224-320 (Delta E*ab <= 3).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import gamma22_rmse_u8, median3
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_sobol_matrices_match_reference_words(oracle):
+    golden = json.load(open(os.path.join(HERE, "golden", "sobol_matrices_dim01.json")))["words"]
+    assert oracle.sobol_matrices().tolist() == golden
+
+
+def test_sobol_sample_index_is_a_permutation(oracle):
+    # even log2(spp): for a fixed pixel and dimension the spp sample indices map to distinct Sobol indices whose
+    # high (pixel) digits are constant => a permutation of one 2^log2spp block (z_sobol_sampler.rs:101-156)
+    w = h = 64
+    for spp in (16, 64):
+        for dim in (0, 3, 7):
+            idx = [oracle.sobol_index(w, h, spp, 5, 9, s, dim) for s in range(spp)]
+            assert len(set(idx)) == spp
+            assert len({i >> int(np.log2(spp)) for i in idx}) == 1
+
+
+def test_sobol_odd_log2_duplicate_pair_quirk(oracle):
+    # reference quirk (F6-ii): for odd log2(spp) sample indices 2k and 2k+1 collide (z_sobol_sampler.rs:147-153)
+    w = h = 64
+    spp = 8
+    idx = [oracle.sobol_index(w, h, spp, 3, 4, s, 2) for s in range(spp)]
+    assert all(idx[2 * k] == idx[2 * k + 1] for k in range(spp // 2))
+
+
+def test_sobol_u32_morton_aliasing(oracle):
+    # reference quirk (F6-i): 1920x1080 @ 4096 spp needs 34 Morton bits; x bit 10 / y bit 10 fall off the u32
+    xys = np.array([[5, 7, 123], [5 + 1024, 7, 123], [5, 7 + 1024, 123]], dtype=np.uint32)
+    bits = oracle.probe_sobol(1920, 1080, 4096, 0, xys, "122")
+    assert (bits[0] == bits[1]).all() and (bits[0] == bits[2]).all()
+    xys2 = np.array([[5, 7, 123], [5 + 512, 7, 123]], dtype=np.uint32)
+    b2 = oracle.probe_sobol(1920, 1080, 4096, 0, xys2, "122")
+    assert not (b2[0] == b2[1]).all()
+
+
+def test_sobol_stratification(oracle):
+    # (0,2)-sequence property survives Owen scrambling: the first 16 2-D points of a pixel land in the 16 cells of 4x4
+    xys = np.array([[11, 3, s] for s in range(16)], dtype=np.uint32)
+    bits = oracle.probe_sobol(64, 64, 16, 7, xys, "12")     # the camera sample is the 2-D draw after dim 0
+    u = bits[:, 1] >> 30
+    v = bits[:, 2] >> 30
+    assert len(set(zip(u.tolist(), v.tolist()))) == 16
+
+
+@pytest.fixture(scope="module")
+def small_scene(oracle, pkg):
+    sc = oracle.new_scene()
+    cam = pkg.scenes.load_scene(sc, 3, 48, 36, tex_size=128)
+    return sc, cam
+
+
+def test_fast_mode_equals_faithful_mode(oracle, pkg, small_scene):
+    """The t_max-shrinking traversal used for golden generation returns exactly the faithful traversal's hits."""
+    sc, cam = small_scene
+    rng = np.random.default_rng(3)
+    n = 4000
+    o = np.tile(np.array([[0.0, 0.0, 0.0]], np.float32), (n, 1))
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 2] = -np.abs(d[:, 2]) - 0.5
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    oracle.set_faithful(sc, True)
+    a = oracle_probe = sc.probe_intersect(o, d)
+    oracle.set_faithful(sc, False)
+    b = sc.probe_intersect(o, d)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    prm = pkg.make_params(4, "mis", "sobol")
+    oracle.set_faithful(sc, True)
+    acc_a, _ = oracle.render_accum(sc, cam, prm, threads=8)
+    oracle.set_faithful(sc, False)
+    acc_b, _ = oracle.render_accum(sc, cam, prm, threads=8)
+    assert np.array_equal(acc_a, acc_b)
+
+
+def test_pt_nee_mis_consistency(oracle, pkg):
+    """renderer_consistency_test.rs:319-353 at reduced size: scene 3, random sampler, 3x3 median, gamma-2.2 RMSE."""
+    sc = oracle.new_scene()
+    cam = pkg.scenes.load_scene(sc, 3, 64, 48, tex_size=128)
+    oracle.set_faithful(sc, False)
+    imgs = {}
+    for strat in ("pt", "nee", "mis"):
+        prm = pkg.make_params(2048, strat, "random")
+        imgs[strat] = median3(oracle.quantize_u8(oracle.render(sc, cam, prm, threads=8)))
+    assert gamma22_rmse_u8(imgs["pt"], imgs["nee"]) <= 0.013
+    assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
+
+
+def test_rgb2spec_round_trip_delta_e(oracle, pkg):
+    """rgb_to_spec/tests/test.rs:224-320: 16^3 grid, RGB -> coefficients -> spectrum x D65 x CMF -> RGB, Delta E*ab <= 3
+    (the reference only prints the violation count; here it is asserted for in-gamut, not-too-dark colours)."""
+    p = pkg.scenes.presets()
+    sc = oracle.new_scene()
+    sc.set_rgb2spec(pkg.scenes.srgb_table())
+    g = (np.arange(16) + 0.5) / 16.0
+    rgb_lin = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    enc = np.where(rgb_lin <= 0.0031308, 12.92 * rgb_lin, 1.055 * rgb_lin ** (1 / 2.4) - 0.055).astype(np.float32)
+    c = oracle.rgb2spec(sc, enc).astype(np.float64)
+    t = np.arange(470) / 470.0
+    spec = 1.0 / (1.0 + np.exp(-(c[:, 0:1] * t * t + c[:, 1:2] * t + c[:, 2:3])))
+    d65 = p["cie_illum_d6500"].astype(np.float64)
+    xyz = np.stack([(spec * d65 * p[k].astype(np.float64)).sum(1) for k in ("cie_x", "cie_y", "cie_z")], -1)
+    M = np.array([[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]])
+    Minv = np.linalg.inv(M)
+
+    def lab(x):
+        w = Minv @ np.ones(3)
+        f = lambda q: np.where(q > (6 / 29) ** 3, np.cbrt(q), q / (3 * (6 / 29) ** 2) + 4 / 29)
+        fx, fy, fz = f(x[:, 0] / w[0]), f(x[:, 1] / w[1]), f(x[:, 2] / w[2])
+        return np.stack([116 * fy - 16, 500 * (fx - fy), 200 * (fy - fz)], -1)
+
+    de = np.linalg.norm(lab(xyz) - lab(rgb_lin @ Minv.T), axis=1)
+    assert np.percentile(de, 99) <= 3.0, (de.max(), np.percentile(de, 99))
+    assert de.max() <= 6.0
+
+
+def test_film_resolve_and_quantize(oracle):
+    acc = np.array([[[0.0, 4.0, -1.0]]], dtype=np.float32)
+    out = oracle.film_resolve(acc, 4)[0, 0]
+    # mean, clip >= 0, Reinhard c/(1+c), sRGB OETF (sensor.rs:81-88)
+    assert out[0] == 0.0 and out[2] == 0.0
+    assert abs(out[1] - (1.055 * 0.5 ** (1 / 2.4) - 0.055)) < 1e-6
+    assert oracle.quantize_u8(np.array([0.999, 1.0], np.float32)).tolist() == [254, 255]

@@ -1,0 +1,405 @@
+// extern "C" boundary of libmi355pt.so (include/mi355pt.h).  Host C++ only; the compute lives in pt_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355pt.h"
+#include "layout.hpp"
+#include "scene.hpp"
+
+namespace pt {
+hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, unsigned*, DevStats*, bool, int, hipStream_t);
+hipError_t launch_probe_radiance(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, unsigned*, const uint32_t*, uint32_t, float*,
+                                 float*, float*, int, hipStream_t);
+hipError_t launch_resolve(const float*, uint32_t, uint32_t, float*, hipStream_t);
+hipError_t launch_probe_sobol(uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t*, hipStream_t);
+hipError_t launch_probe_intersect(const DevScene&, const float*, const float*, uint32_t, float*, uint32_t*, uint32_t*, float*, hipStream_t);
+hipError_t launch_probe_occluded(const DevScene&, const float*, const float*, const float*, uint32_t, uint8_t*, hipStream_t);
+uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed);
+}  // namespace pt
+
+using namespace pt;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(MI355PT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+static const uint32_t CIE_CMF_BITS[470 * 4] = {
+#include "cie_cmf.inc"
+};
+
+struct mi355pt_scene {
+    SceneImpl impl;
+};
+
+namespace {
+
+struct V3 { float x, y, z; };
+V3 cross3(V3 a, V3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+V3 norm3(V3 a) { float r = 1.0f / std::sqrt((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); return {a.x * r, a.y * r, a.z * r}; }
+
+uint32_t log2_int(uint32_t v) { return v == 0 ? 0 : 31 - (uint32_t)__builtin_clz(v); }
+uint32_t round_up_pow2(uint32_t v) { return v <= 1 ? 1 : 1u << (32 - __builtin_clz(v - 1)); }
+
+DevCamera make_camera(const mi355pt_camera* c) {
+    DevCamera d{};
+    V3 f = norm3(V3{c->direction[0], c->direction[1], c->direction[2]});       // set_look_to normalises (camera.rs:46-48)
+    V3 up = norm3(V3{c->up[0], c->up[1], c->up[2]});
+    V3 s = norm3(cross3(f, up));                                                // glam Mat3::look_to_rh
+    V3 u = cross3(s, f);
+    d.s[0] = s.x; d.s[1] = s.y; d.s[2] = s.z; d.u[0] = u.x; d.u[1] = u.y; d.u[2] = u.z; d.f[0] = f.x; d.f[1] = f.y; d.f[2] = f.z;
+    float fov_rad = c->fov_deg * (3.14159265358979323846f / 180.0f);
+    d.tan_half_fov = std::tan(fov_rad / 2.0f);
+    d.aspect = (float)c->width / (float)c->height;
+    d.width = c->width; d.height = c->height;
+    return d;
+}
+
+// GamutSrgb::new().xyz_to_rgb() (color/src/gamut.rs:29-63), glam Mat3 arithmetic in f32
+void srgb_xyz_to_rgb(float out_rowmajor[9]) {
+    auto xy = [](float x, float y) { return V3{x * 1.0f / y, 1.0f, (1.0f - x - y) * 1.0f / y}; };
+    V3 r = xy(0.64f, 0.33f), g = xy(0.30f, 0.60f), b = xy(0.15f, 0.06f), w = xy(0.3127f, 0.3290f);
+    auto inv = [](V3 x, V3 y, V3 z, V3 o[3]) {   // returns columns of the inverse
+        V3 t0 = cross3(y, z), t1 = cross3(z, x), t2 = cross3(x, y);
+        float det = (z.x * t2.x) + (z.y * t2.y) + (z.z * t2.z);
+        float id = 1.0f / det;
+        V3 r0{t0.x * id, t0.y * id, t0.z * id}, r1{t1.x * id, t1.y * id, t1.z * id}, r2{t2.x * id, t2.y * id, t2.z * id};
+        o[0] = V3{r0.x, r1.x, r2.x}; o[1] = V3{r0.y, r1.y, r2.y}; o[2] = V3{r0.z, r1.z, r2.z};
+    };
+    auto mulv = [](const V3 m[3], V3 v) {
+        return V3{m[0].x * v.x + m[1].x * v.y + m[2].x * v.z, m[0].y * v.x + m[1].y * v.y + m[2].y * v.z, m[0].z * v.x + m[1].z * v.y + m[2].z * v.z};
+    };
+    V3 rgb[3] = {r, g, b}, irgb[3];
+    inv(r, g, b, irgb);
+    V3 c = mulv(irgb, w);
+    V3 r2x[3] = {V3{rgb[0].x * c.x, rgb[0].y * c.x, rgb[0].z * c.x}, V3{rgb[1].x * c.y, rgb[1].y * c.y, rgb[1].z * c.y},
+                 V3{rgb[2].x * c.z, rgb[2].y * c.z, rgb[2].z * c.z}};
+    V3 x2r[3];
+    inv(r2x[0], r2x[1], r2x[2], x2r);
+    // row-major: row i = (col0[i], col1[i], col2[i])
+    out_rowmajor[0] = x2r[0].x; out_rowmajor[1] = x2r[1].x; out_rowmajor[2] = x2r[2].x;
+    out_rowmajor[3] = x2r[0].y; out_rowmajor[4] = x2r[1].y; out_rowmajor[5] = x2r[2].y;
+    out_rowmajor[6] = x2r[0].z; out_rowmajor[7] = x2r[1].z; out_rowmajor[8] = x2r[2].z;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+};
+
+struct LaunchCtx {
+    uint64_t* d_hash = nullptr;
+    unsigned* d_counter = nullptr;
+    DevStats* d_stats = nullptr;
+    ~LaunchCtx() { (void)hipFree(d_hash); (void)hipFree(d_counter); (void)hipFree(d_stats); }
+};
+
+int resident_waves() {
+    int dev = 0; (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
+    return prop.multiProcessorCount * 8;   // 2 waves per SIMD: VGPR-heavy kernel, LDS 9.5 KB per wave
+}
+
+DevParams make_params(const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end) {
+    DevParams d{};
+    d.spp = p->spp; d.seed = p->seed; d.max_depth = p->max_depth; d.strategy = p->strategy; d.sampler = p->sampler;
+    d.exposure = p->exposure;
+    d.log2_spp = log2_int(p->spp);                                              // ZSobolSampler::new (:179-196)
+    uint32_t res = round_up_pow2(std::max(cam->width, cam->height));
+    d.n_base4_digits = log2_int(res) + (d.log2_spp + 1) / 2;
+    d.sample_begin = s_begin; d.sample_end = s_end;
+    d.shard_count = p->shard_count ? p->shard_count : 1;
+    d.shard_index = p->shard_count ? p->shard_index : 0;
+    d.tiles_x = (cam->width + 7) / 8; d.tiles_y = (cam->height + 7) / 8;
+    srgb_xyz_to_rgb(d.xyz_to_rgb);
+    return d;
+}
+
+int alloc_launch_ctx(LaunchCtx& lc, uint32_t seed) {
+    std::vector<uint64_t> tab(HASH_TABLE_DIMS);
+    for (int i = 0; i < HASH_TABLE_DIMS; ++i) tab[i] = host_murmur_dim_seed((uint32_t)i, seed);
+    HIP_TRY(hipMalloc((void**)&lc.d_hash, sizeof(uint64_t) * HASH_TABLE_DIMS));
+    HIP_TRY(hipMemcpy(lc.d_hash, tab.data(), sizeof(uint64_t) * HASH_TABLE_DIMS, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&lc.d_counter, sizeof(unsigned)));
+    HIP_TRY(hipMalloc((void**)&lc.d_stats, sizeof(DevStats)));
+    return MI355PT_OK;
+}
+
+int check_args(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p) {
+    if (!s || !cam || !p) return fail(MI355PT_E_INVALID, "null argument");
+    if (!s->impl.built) return fail(MI355PT_E_NOT_BUILT, "scene not built");
+    if (cam->width == 0 || cam->height == 0 || p->spp == 0) return fail(MI355PT_E_INVALID, "empty image or spp == 0");
+    if (p->strategy > 2 || p->sampler > 1) return fail(MI355PT_E_INVALID, "bad strategy/sampler");
+    if (p->shard_count && p->shard_index >= p->shard_count) return fail(MI355PT_E_INVALID, "bad shard");
+    return MI355PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mi355pt_last_error(void) { return g_err.c_str(); }
+const char* mi355pt_version(void) { return "mi355pt 0.1.0 (gfx950)"; }
+
+int mi355pt_scene_create(mi355pt_scene** out) {
+    if (!out) return fail(MI355PT_E_INVALID, "null out");
+    *out = new (std::nothrow) mi355pt_scene();
+    return *out ? MI355PT_OK : fail(MI355PT_E_INVALID, "allocation failed");
+}
+void mi355pt_scene_destroy(mi355pt_scene* s) { delete s; }
+
+int mi355pt_scene_set_rgb2spec(mi355pt_scene* s, const float* table, size_t n) {
+    if (!s || !table || n != (size_t)(64 + 3 * 64 * 64 * 64 * 3)) return fail(MI355PT_E_INVALID, "rgb2spec table must have 64 + 3*64^3*3 floats");
+    s->impl.table.assign(table, table + n);
+    return MI355PT_OK;
+}
+int mi355pt_scene_add_lut470(mi355pt_scene* s, const float* v, uint32_t* id) {
+    if (!s || !v || !id) return fail(MI355PT_E_INVALID, "null argument");
+    s->impl.luts.emplace_back(v, v + 470);
+    *id = (uint32_t)s->impl.luts.size() - 1;
+    return MI355PT_OK;
+}
+int mi355pt_scene_add_tex_rgb8(mi355pt_scene* s, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t* id) {
+    if (!s || !rgb || !id || w == 0 || h == 0) return fail(MI355PT_E_INVALID, "bad texture");
+    SceneImpl::Tex t; t.w = w; t.h = h; t.rgb.assign(rgb, rgb + (size_t)w * h * 3);
+    s->impl.textures.push_back(std::move(t));
+    *id = (uint32_t)s->impl.textures.size() - 1;
+    return MI355PT_OK;
+}
+int mi355pt_scene_add_mesh(mi355pt_scene* s, const float* pos, const float* nrm, const float* uv, const float* tri_tangent, const uint32_t* idx,
+                           uint32_t nv, uint32_t nt, uint32_t* out) {
+    if (!s || !pos || !nrm || !idx || !out || nv == 0 || nt == 0) return fail(MI355PT_E_INVALID, "bad mesh");
+    if ((uv != nullptr) != (tri_tangent != nullptr)) return fail(MI355PT_E_INVALID, "uv and tri_tangent must be given together");
+    for (size_t i = 0; i < (size_t)nt * 3; ++i) if (idx[i] >= nv) return fail(MI355PT_E_INVALID, "vertex index out of range");
+    HostMesh m; m.n_vert = nv; m.n_tri = nt;
+    m.pos.assign(pos, pos + (size_t)nv * 3);
+    m.nrm.resize((size_t)nv * 3);
+    for (uint32_t i = 0; i < nv; ++i) {   // Normal::new normalises and Normal::from renormalises (normal.rs:18-20,93-100)
+        V3 n = norm3(norm3(V3{nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]}));
+        m.nrm[3 * i] = n.x; m.nrm[3 * i + 1] = n.y; m.nrm[3 * i + 2] = n.z;
+    }
+    if (uv) { m.uv.assign(uv, uv + (size_t)nv * 2); m.tangent.assign(tri_tangent, tri_tangent + (size_t)nt * 3); }
+    m.idx.assign(idx, idx + (size_t)nt * 3);
+    s->impl.meshes.push_back(std::move(m));
+    *out = (uint32_t)s->impl.meshes.size() - 1;
+    return MI355PT_OK;
+}
+int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d, uint32_t* out) {
+    if (!s || !d || !out) return fail(MI355PT_E_INVALID, "null argument");
+    SceneImpl& im = s->impl;
+    DevMaterial m{};
+    std::string err;
+    int rc;
+    m.type = d->type;
+    m.normal_tex = d->normal_tex; m.normal_flip_y = d->normal_flip_y; m.thin = d->thin;
+    m.intensity = d->intensity; m.roughness = d->roughness; m.metallic = d->metallic; m.ior = d->ior;
+    m.cc_ior = d->clearcoat_ior; m.cc_roughness = d->clearcoat_roughness; m.cc_thickness = d->clearcoat_thickness;
+    if (d->normal_tex != MI355PT_NONE && d->normal_tex >= im.textures.size()) return fail(MI355PT_E_INVALID, "bad normal texture id");
+    switch (d->type) {
+        case MI355PT_MAT_LAMBERT:
+            if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, err);
+            break;
+        case MI355PT_MAT_EMISSIVE:
+            if ((rc = im.lower_spectrum(d->color, &m.color, false, &err))) return fail(rc, "emissive radiance: " + err);
+            break;
+        case MI355PT_MAT_GLASS:
+        case MI355PT_MAT_PLASTIC:
+            if ((rc = im.lower_spectrum(d->eta, &m.eta, false, &err))) return fail(rc, "eta: " + err);
+            if ((rc = im.lower_spectrum(d->color, &m.color, d->type == MI355PT_MAT_PLASTIC, &err))) return fail(rc, err);
+            if (d->roughness >= 1e-3f) return fail(MI355PT_E_INVALID, "rough dielectrics are not implemented on the device yet (roughness must be < 1e-3)");
+            break;
+        default:
+            return fail(MI355PT_E_INVALID, "material type not implemented on the device yet");
+    }
+    im.materials.push_back(m);
+    im.mat_descs.push_back(*d);
+    *out = (uint32_t)im.materials.size() - 1;
+    return MI355PT_OK;
+}
+int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, const float* l2w) {
+    if (!s || !l2w) return fail(MI355PT_E_INVALID, "null argument");
+    if (geom >= s->impl.meshes.size() || mat >= s->impl.materials.size()) return fail(MI355PT_E_INVALID, "bad geometry/material id");
+    HostInstance hi; hi.geom = geom; hi.mat = mat; std::memcpy(hi.l2w, l2w, sizeof(float) * 16);
+    s->impl.instances.push_back(hi);
+    return MI355PT_OK;
+}
+int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam) {
+    if (!s || !cam) return fail(MI355PT_E_INVALID, "null argument");
+    std::string err;
+    float cmf[470 * 4];
+    std::memcpy(cmf, CIE_CMF_BITS, sizeof(cmf));
+    int rc = s->impl.build(cam, cmf, &err);
+    return rc ? fail(rc, err) : MI355PT_OK;
+}
+
+int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end,
+                                float* d_accum, void* hip_stream, mi355pt_stats* stats) {
+    int rc = check_args(s, cam, p);
+    if (rc) return rc;
+    if (!d_accum || s_end > p->spp || s_begin >= s_end) return fail(MI355PT_E_INVALID, "bad sample range or null accumulator");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DevCamera dc = make_camera(cam);
+    DevParams dp = make_params(cam, p, s_begin, s_end);
+    uint32_t n_tiles_total = dp.tiles_x * dp.tiles_y;
+    uint32_t n_tiles = n_tiles_total > dp.shard_index ? (n_tiles_total - dp.shard_index + dp.shard_count - 1) / dp.shard_count : 0;
+    if (n_tiles == 0) return MI355PT_OK;
+    int waves = resident_waves();
+    // split the sample range only when there are too few tiles to fill the chip (small images / many shards)
+    uint32_t n_samples = s_end - s_begin;
+    uint32_t chunks = 1;
+    while (n_tiles * chunks < (uint32_t)waves * 4 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 8) chunks *= 2;
+    dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
+    dp.n_work = n_tiles * chunks;
+    LaunchCtx lc;
+    if ((rc = alloc_launch_ctx(lc, p->seed))) return rc;
+    HIP_TRY(hipMemsetAsync(lc.d_counter, 0, sizeof(unsigned), stream));
+    bool want_stats = stats && p->collect_stats;
+    if (want_stats) HIP_TRY(hipMemsetAsync(lc.d_stats, 0, sizeof(DevStats), stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (stats) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
+    int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)waves);
+    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc.d_hash, d_accum, lc.d_counter, lc.d_stats, want_stats, grid, stream));
+    if (stats) {
+        HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        std::memset(stats, 0, sizeof(*stats));
+        stats->kernel_ms = ms; stats->launches = 1;
+        if (want_stats) {
+            DevStats h;
+            HIP_TRY(hipMemcpy(&h, lc.d_stats, sizeof(h), hipMemcpyDeviceToHost));
+            stats->samples = h.samples; stats->closest_rays = h.closest_rays; stats->shadow_rays = h.shadow_rays;
+            stats->nodes_closest = h.nodes_closest; stats->tris_closest = h.tris_closest; stats->nodes_shadow = h.nodes_shadow;
+            stats->tris_shadow = h.tris_shadow; stats->closest_hits = h.closest_hits; stats->bounces = h.bounces;
+            stats->spectrum_evals = h.spectrum_evals; stats->textured_lookups = h.textured_lookups;
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    } else {
+        // the launch context is freed on return: wait for the kernel (callers that want overlap pass stats = NULL
+        // only for whole-frame work, where this wait is the frame's natural end)
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return MI355PT_OK;
+}
+
+int mi355pt_film_resolve_device(const float* d_accum, uint32_t n_pixels, uint32_t spp, float* d_out, void* hip_stream) {
+    if (!d_accum || !d_out || spp == 0) return fail(MI355PT_E_INVALID, "bad resolve arguments");
+    HIP_TRY(launch_resolve(d_accum, n_pixels * 3, spp, d_out, (hipStream_t)hip_stream));
+    return MI355PT_OK;
+}
+
+int mi355pt_render(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, float* out_rgb, mi355pt_stats* stats) {
+    int rc = check_args(s, cam, p);
+    if (rc) return rc;
+    if (!out_rgb) return fail(MI355PT_E_INVALID, "null output");
+    size_t n = (size_t)cam->width * cam->height * 3;
+    float *d_acc = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_acc, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&d_out, n * sizeof(float)));
+    HIP_TRY(hipMemset(d_acc, 0, n * sizeof(float)));
+    rc = mi355pt_render_accum_device(s, cam, p, 0, p->spp, d_acc, nullptr, stats);
+    if (!rc) rc = mi355pt_film_resolve_device(d_acc, cam->width * cam->height, p->spp, d_out, nullptr);
+    if (!rc) { hipError_t e = hipMemcpy(out_rgb, d_out, n * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI355PT_E_DEVICE, hipGetErrorString(e)); }
+    (void)hipFree(d_acc); (void)hipFree(d_out);
+    return rc;
+}
+
+int mi355pt_quantize_u8(const float* rgb, size_t n, uint8_t* out) {
+    if (!rgb || !out) return fail(MI355PT_E_INVALID, "null argument");
+    for (size_t i = 0; i < n; ++i) {   // Rust `as u8`: saturating, NaN -> 0 (renderer.rs:141-143)
+        float v = rgb[i] * 255.0f;
+        out[i] = std::isnan(v) ? 0 : (v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (uint8_t)v));
+    }
+    return MI355PT_OK;
+}
+
+// ---------------- probes ----------------
+
+int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t seed, const uint32_t* xys, uint32_t n, const char* pattern,
+                        uint32_t* out_bits) {
+    if (!xys || !pattern || !out_bits || spp == 0) return fail(MI355PT_E_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI355PT_E_NO_DEVICE, "no HIP device");
+    uint32_t n_pat = (uint32_t)std::strlen(pattern), per = 0;
+    for (uint32_t i = 0; i < n_pat; ++i) per += pattern[i] == '2' ? 2 : 1;
+    if (n == 0 || per == 0) return MI355PT_OK;
+    uint32_t log2_spp = log2_int(spp);
+    uint32_t nb4 = log2_int(round_up_pow2(std::max(width, height))) + (log2_spp + 1) / 2;
+    DevBuf<uint32_t> d_xys, d_out; DevBuf<uint8_t> d_pat;
+    HIP_TRY(d_xys.alloc((size_t)n * 3)); HIP_TRY(d_out.alloc((size_t)n * per)); HIP_TRY(d_pat.alloc(n_pat));
+    HIP_TRY(hipMemcpy(d_xys.p, xys, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pat.p, pattern, n_pat, hipMemcpyHostToDevice));
+    HIP_TRY(launch_probe_sobol(width, seed, log2_spp, nb4, d_xys.p, n, d_pat.p, n_pat, per, d_out.p, nullptr));
+    HIP_TRY(hipMemcpy(out_bits, d_out.p, sizeof(uint32_t) * (size_t)n * per, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+
+int mi355pt_probe_intersect(const mi355pt_scene* s, const float* o, const float* d, uint32_t n, float* out_t, uint32_t* out_inst, uint32_t* out_tri,
+                            float* out_n) {
+    if (!s || !o || !d || !out_t || !out_inst || !out_tri) return fail(MI355PT_E_INVALID, "null argument");
+    if (!s->impl.built) return fail(MI355PT_E_NOT_BUILT, "scene not built");
+    if (n == 0) return MI355PT_OK;
+    DevBuf<float> d_o, d_d, d_t, d_n; DevBuf<uint32_t> d_i, d_tr;
+    HIP_TRY(d_o.alloc((size_t)n * 3)); HIP_TRY(d_d.alloc((size_t)n * 3)); HIP_TRY(d_t.alloc(n)); HIP_TRY(d_n.alloc((size_t)n * 3));
+    HIP_TRY(d_i.alloc(n)); HIP_TRY(d_tr.alloc(n));
+    HIP_TRY(hipMemcpy(d_o.p, o, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d.p, d, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    HIP_TRY(launch_probe_intersect(s->impl.dev, d_o.p, d_d.p, n, d_t.p, d_i.p, d_tr.p, d_n.p, nullptr));
+    HIP_TRY(hipMemcpy(out_t, d_t.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_inst, d_i.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_tri, d_tr.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    if (out_n) HIP_TRY(hipMemcpy(out_n, d_n.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+
+int mi355pt_probe_occluded(const mi355pt_scene* s, const float* o, const float* d, const float* tmax, uint32_t n, uint8_t* out) {
+    if (!s || !o || !d || !tmax || !out) return fail(MI355PT_E_INVALID, "null argument");
+    if (!s->impl.built) return fail(MI355PT_E_NOT_BUILT, "scene not built");
+    if (n == 0) return MI355PT_OK;
+    DevBuf<float> d_o, d_d, d_t; DevBuf<uint8_t> d_out;
+    HIP_TRY(d_o.alloc((size_t)n * 3)); HIP_TRY(d_d.alloc((size_t)n * 3)); HIP_TRY(d_t.alloc(n)); HIP_TRY(d_out.alloc(n));
+    HIP_TRY(hipMemcpy(d_o.p, o, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d.p, d, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_t.p, tmax, sizeof(float) * n, hipMemcpyHostToDevice));
+    HIP_TRY(launch_probe_occluded(s->impl.dev, d_o.p, d_d.p, d_t.p, n, d_out.p, nullptr));
+    HIP_TRY(hipMemcpy(out, d_out.p, n, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+
+int mi355pt_probe_radiance(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, const uint32_t* xys, uint32_t n, float* out_L,
+                           float* out_lambda, float* out_pdf) {
+    int rc = check_args(s, cam, p);
+    if (rc) return rc;
+    if (!xys || !out_L || !out_lambda || !out_pdf) return fail(MI355PT_E_INVALID, "null argument");
+    if (n == 0) return MI355PT_OK;
+    DevCamera dc = make_camera(cam);
+    DevParams dp = make_params(cam, p, 0, p->spp);
+    dp.chunks = 1; dp.chunk_size = 1; dp.n_work = (n + 63) / 64;
+    LaunchCtx lc;
+    if ((rc = alloc_launch_ctx(lc, p->seed))) return rc;
+    HIP_TRY(hipMemset(lc.d_counter, 0, sizeof(unsigned)));
+    DevBuf<uint32_t> d_xys; DevBuf<float> d_L, d_lam, d_pdf;
+    HIP_TRY(d_xys.alloc((size_t)n * 3)); HIP_TRY(d_L.alloc((size_t)n * 4)); HIP_TRY(d_lam.alloc((size_t)n * 4)); HIP_TRY(d_pdf.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_xys.p, xys, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice));
+    int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)resident_waves());
+    HIP_TRY(launch_probe_radiance(s->impl.dev, dc, dp, lc.d_hash, lc.d_counter, d_xys.p, n, d_L.p, d_lam.p, d_pdf.p, grid, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_L, d_L.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_lambda, d_lam.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_pdf, d_pdf.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// Data layout shared by the host lowering (scene.cpp) and the gfx950 kernels (pt_kernels.hip).
+//
+// Everything the sample loop touches lives in HBM as flat, 16-byte-aligned records sized for
+// whole dwordx4 gathers (lanes of a wave traverse independently, so node/triangle fetches are
+// per-lane gathers; a record that is one or a few aligned 16 B pieces costs the fewest TA cycles):
+//
+//   DevNode      64 B  BVH2 node holding BOTH child boxes + child links      (SURVEY §8d "node 64 B")
+//   DevTri       48 B  render-space triangle, leaf order                     (36 B of positions + pad)
+//   DevTriShade  96 B  per-triangle shading attributes, fetched once per closest hit
+//   DevMaterial  96 B  tagged material record
+//   DevLightTri  48 B  emissive triangle (render space) + area CDF entry
+//   LUTs         470 f32 each; CIE x/y/z interleaved as float4 per nm
+//   rgb2spec     [3][64][64][64] float4 (c0,c1,c2,0) + 64 z nodes
+//   textures     RGBA8 (one dword per texel)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PT_HD __host__ __device__
+#else
+#define PT_HD
+#endif
+
+namespace pt {
+
+constexpr int STACK_DEPTH = 32;        // per-lane traversal stack entries kept in LDS
+constexpr int MAX_LEAF_TRIS = 4;
+constexpr int MAX_BUILD_DEPTH = 30;    // builder guarantees depth <= this (< STACK_DEPTH)
+constexpr int HASH_TABLE_DIMS = 192;   // precomputed murmur(dimension, seed) entries
+
+struct alignas(16) DevNode {
+    // child i box: lo = (bx[i], by[i], bz[i]) hi = (bx[2+i], by[2+i], bz[2+i])
+    float bx[4];   // lo0.x lo1.x hi0.x hi1.x
+    float by[4];
+    float bz[4];
+    int32_t child[2];   // >= 0: node index; < 0: leaf, see leaf_first/leaf_count
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevNode) == 64, "node must be 64 B");
+PT_HD inline int32_t make_leaf(uint32_t first, uint32_t count) { return (int32_t)(0x80000000u | (first << 3) | (count - 1)); }
+PT_HD inline uint32_t leaf_first(int32_t c) { return ((uint32_t)c & 0x7fffffffu) >> 3; }
+PT_HD inline uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1; }
+
+struct alignas(16) DevTri {
+    float p0[3]; float p1x;
+    float p1yz[2]; float p2xy[2];
+    float p2z; uint32_t pad[3];
+};
+static_assert(sizeof(DevTri) == 48, "tri must be 48 B");
+
+struct alignas(16) DevTriShade {
+    float n0[3]; float n1x;        // LOCAL-space vertex normals (unit)
+    float n1yz[2]; float n2xy[2];
+    float n2z; float tangent[3];   // LOCAL-space per-triangle tangent (valid if flags & 1)
+    float uv0[2]; float uv1[2];
+    float uv2[2]; uint32_t material; uint32_t instance;
+    uint32_t flags;                // bit0: has uv/tangent, bit1: emissive
+    uint32_t light;                // light index if emissive else ~0
+    uint32_t local_tri;            // triangle index inside its mesh
+    float light_pdf_area;          // (1/area_i) * (cdf_i - cdf_{i-1}) for emissive tris (emissive_triangle_mesh.rs:334-353)
+};
+static_assert(sizeof(DevTriShade) == 96, "shade record must be 96 B");
+
+struct alignas(16) DevInstance {
+    float lin[9];      // linear part of local_to_render, column-major 3x3 (vectors)
+    float nrm[9];      // inverse-transpose of lin, column-major 3x3 (normals)
+    uint32_t identity; // 1: both are the identity, skip the multiplies
+    uint32_t pad;
+};
+static_assert(sizeof(DevInstance) == 80, "instance record");
+
+enum : uint32_t { SPK_CONSTANT = 0, SPK_SIGMOID = 1, SPK_LUT = 2, SPK_TEXTURE = 3 };
+struct DevSpectrum {
+    uint32_t kind;
+    uint32_t id;       // LUT index or texture index
+    float c[3];        // constant in c[0] or sigmoid coefficients
+    uint32_t pad[3];
+};
+static_assert(sizeof(DevSpectrum) == 32, "spectrum param");
+
+enum : uint32_t { MT_LAMBERT = 0, MT_EMISSIVE = 1, MT_GLASS = 2, MT_PLASTIC = 3, MT_CLEARCOAT = 4 };
+struct alignas(16) DevMaterial {
+    uint32_t type;
+    uint32_t normal_tex;   // ~0 = none
+    uint32_t normal_flip_y;
+    uint32_t thin;
+    float intensity, roughness, metallic, ior;
+    float cc_ior, cc_roughness, cc_thickness, pad0;
+    DevSpectrum color;
+    DevSpectrum eta;       // glass: LUT, plastic: constant
+    DevSpectrum cc_tint;
+};
+static_assert(sizeof(DevMaterial) == 144, "material record");
+
+struct alignas(16) DevLightTri {
+    float p0[3]; float p1x;
+    float p1yz[2]; float p2xy[2];
+    float p2z; float cdf;   // area_table entry (normalised running sum)
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevLightTri) == 48, "light tri");
+
+struct DevLight {
+    uint32_t first_tri, n_tris;   // into light_tris
+    uint32_t material;
+    float area_sum;
+};
+
+struct DevTexture {
+    uint32_t offset;   // texel offset into the RGBA8 pool
+    uint32_t w, h, pad;
+};
+
+struct DevScene {
+    const DevNode* nodes;
+    const DevTri* tris;
+    const DevTriShade* shade;
+    const DevInstance* instances;
+    const DevMaterial* materials;
+    const DevLight* lights;
+    const DevLightTri* light_tris;
+    const float* luts;            // [n_luts][470]
+    const float* cmf;             // [470][4]  (xbar, ybar, zbar, 0)
+    const float* rgb2spec;        // [3][64][64][64][4]
+    const float* z_nodes;         // [64]
+    const uint32_t* texels;       // RGBA8 pool
+    const DevTexture* textures;
+    uint32_t n_nodes, n_tris, n_lights, n_materials;
+    int32_t root;                 // root link (node index, or leaf if the scene has <= MAX_LEAF_TRIS tris)
+    uint32_t pad[3];
+};
+
+struct DevCamera {
+    float s[3], u[3], f[3];       // look_to_rh basis (camera.rs:58-62)
+    float tan_half_fov, aspect;
+    uint32_t width, height;
+};
+
+struct DevParams {
+    uint32_t spp, seed, max_depth, strategy, sampler;
+    float exposure;
+    uint32_t log2_spp, n_base4_digits;     // ZSobolSampler::new (z_sobol_sampler.rs:179-196)
+    uint32_t sample_begin, sample_end;
+    uint32_t shard_index, shard_count;
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_work;                        // tiles * sample chunks handled by this launch
+    uint32_t chunks, chunk_size;            // sample-range split per tile (1 = none)
+    float xyz_to_rgb[9];                    // row-major sRGB matrix (gamut.rs:50-63)
+};
+
+struct DevStats {
+    unsigned long long samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;
+    unsigned long long closest_hits, bounces, spectrum_evals, textured_lookups;
+};
+
+}  // namespace pt

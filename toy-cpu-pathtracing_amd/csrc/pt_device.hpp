@@ -1,0 +1,448 @@
+// gfx950 device functions of the spectral path tracer: vector math, Sobol/Owen sampling, spectrum
+// evaluation, BVH traversal with per-lane LDS stacks, watertight triangle test.
+// Hand-written for CDNA4 wave64; no host fallbacks.  Reference citations are file:line under
+// /root/reference (the algorithms' semantics come from there; the structure does not).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.hpp"
+
+namespace pt {
+
+#define PT_DEV __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+struct f2 { float x, y; };
+PT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+PT_DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+PT_DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+PT_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+PT_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+PT_DEV f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+PT_DEV float dot(f3 a, f3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+PT_DEV f3 cross(f3 a, f3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+PT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+PT_DEV f3 normalize(f3 a) { return a * (1.0f / length(a)); }   // glam: v * (1/len)
+PT_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+PT_DEV float sgn1(float x) { return copysignf(1.0f, x); }       // f32::signum for non-NaN input
+PT_DEV float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float LAMBDA_MIN = 360.0f, LAMBDA_MAX = 830.0f;
+
+// ---------------------------------------------------------------------------------------------
+// ZSobolSampler (renderer/src/sampler/z_sobol_sampler.rs) — integer-exact.
+// ---------------------------------------------------------------------------------------------
+PT_DEV uint64_t mix_bits(uint64_t v) {                                   // :68-75
+    v ^= v >> 31; v *= 0x7fb5d329728ea185ull;
+    v ^= v >> 27; v *= 0x81dadef4bc2dd44dull;
+    v ^= v >> 33;
+    return v;
+}
+__host__ __device__ inline uint64_t murmur_dim_seed(uint32_t dimension, uint32_t seed) {   // :77-99
+    const uint64_t M = 0xc6a4a7935bd1e995ull;
+    uint64_t h = 8ull * M;
+    uint64_t k = (uint64_t)dimension | ((uint64_t)seed << 32);
+    k *= M; k ^= k >> 47; k *= M;
+    h ^= k; h *= M;
+    h ^= h >> 47; h *= M; h ^= h >> 47;
+    return h;
+}
+PT_DEV uint32_t fast_owen(uint32_t v, uint32_t seed) {                  // :3-28
+    v = __brev(v);
+    v ^= v * 0x3d20adeau;
+    v += seed;
+    v *= (seed >> 16) | 1u;
+    v ^= v * 0x05526c56u;
+    v ^= v * 0x53a22864u;
+    return __brev(v);
+}
+PT_DEV uint32_t part1by1(uint32_t x) {   // 16 low bits -> even bit positions
+    x &= 0x0000ffffu;
+    x = (x ^ (x << 8)) & 0x00ff00ffu;
+    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
+    x = (x ^ (x << 2)) & 0x33333333u;
+    x = (x ^ (x << 1)) & 0x55555555u;
+    return x;
+}
+// encode_morton2 truncated to u32 exactly like the reference (:53-66): bits >= 16 of x/y fall off.
+PT_DEV uint32_t encode_morton2_u32(uint32_t x, uint32_t y) { return (part1by1(y) << 1) | part1by1(x); }
+
+// The 24 base-4 digit permutations (:102-127), 2 bits per digit packed into a byte.
+__device__ const uint8_t PERM_PACKED[24] = {
+    0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D,
+    0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
+
+PT_DEV uint64_t sobol_sample_index(uint32_t morton, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits) {   // :101-156
+    uint64_t sample_index = 0;
+    const bool pow2 = (log2_spp & 1u) != 0;
+    const int last = pow2 ? 1 : 0;
+    const uint64_t dmix = 0x55555555ull * (uint64_t)dimension;
+    for (int i = (int)n_base4_digits - 1; i >= last; --i) {
+        int shift = 2 * i - (pow2 ? 1 : 0);
+        uint32_t digit = (uint32_t)((uint64_t)morton >> shift) & 3u;
+        uint64_t higher = (uint64_t)morton >> (shift + 2);
+        // (mix >> 24) % 24 on a 40-bit value with 32-bit ops: 2^32 mod 24 == 16
+        uint64_t mx = mix_bits(higher ^ dmix) >> 24;
+        uint32_t p = (((uint32_t)(mx >> 32) * 16u) + ((uint32_t)mx % 24u)) % 24u;
+        digit = ((uint32_t)PERM_PACKED[p] >> (2u * digit)) & 3u;
+        sample_index |= (uint64_t)digit << shift;
+    }
+    if (pow2) {
+        // reference quirk: `morton & i` with i == 0 after the loop, so only the hashed bit survives (:147-153)
+        sample_index |= mix_bits(((uint64_t)morton >> 1) ^ dmix) & 1ull;
+    }
+    return sample_index;
+}
+// Generator matrices, dimension 0: identity (van der Corput) => bit reversal of the low 32 index bits;
+// columns 32..51 are zero (sobol_matrices.rs:7, first 52 words).
+PT_DEV uint32_t sobol_dim0(uint64_t a) { return __brev((uint32_t)a); }
+// dimension 1: column j has row i set iff (j & i) == i, periodic in j mod 32 (words 52..103).  The product is a
+// GF(2) superset-sum (zeta) transform = 5 butterfly stages, then bit reversal.
+PT_DEV uint32_t sobol_dim1(uint64_t a) {
+    uint32_t b = (uint32_t)a ^ (uint32_t)(a >> 32);
+    b ^= (b >> 1) & 0x55555555u;
+    b ^= (b >> 2) & 0x33333333u;
+    b ^= (b >> 4) & 0x0f0f0f0fu;
+    b ^= (b >> 8) & 0x00ff00ffu;
+    b ^= (b >> 16) & 0x0000ffffu;
+    return __brev(b);
+}
+PT_DEV float sobol_bits_to_float(uint32_t v) {                           // :174-176
+    return fminf((float)v * 2.3283064365386963e-10f, 0.99999994f);
+}
+
+struct Sampler {
+    uint32_t morton, dimension;
+    uint32_t rkey_lo, rkey_hi;   // random-mode stream key
+};
+
+struct SamplerCtx {
+    uint32_t mode, seed, log2_spp, n_base4_digits, width;
+    const uint64_t* hash_lds;     // murmur(dimension, seed) for dimension < HASH_TABLE_DIMS
+};
+
+PT_DEV void sampler_start(Sampler& s, const SamplerCtx& c, uint32_t px, uint32_t py, uint32_t sample_index) {   // :198-201
+    s.dimension = 0;
+    s.morton = (encode_morton2_u32(px, py) << c.log2_spp) | sample_index;
+    uint64_t k = mix_bits(((uint64_t)(py * c.width + px) << 32) ^ (uint64_t)sample_index ^ ((uint64_t)c.seed << 20) ^ 0x9e3779b97f4a7c15ull);
+    s.rkey_lo = (uint32_t)k; s.rkey_hi = (uint32_t)(k >> 32);
+}
+PT_DEV uint64_t dim_hash(const SamplerCtx& c, uint32_t dimension) {
+    return dimension < (uint32_t)HASH_TABLE_DIMS ? c.hash_lds[dimension] : murmur_dim_seed(dimension, c.seed);
+}
+PT_DEV float random_next(Sampler& s) {
+    uint64_t key = ((uint64_t)s.rkey_hi << 32) | s.rkey_lo;
+    uint64_t h = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(++s.dimension));
+    return (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f;
+}
+PT_DEV uint32_t get_1d_bits(Sampler& s, const SamplerCtx& c) {           // :203-213
+    uint64_t si = sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits);
+    s.dimension += 1;
+    uint64_t h = dim_hash(c, s.dimension);
+    return fast_owen(sobol_dim0(si), (uint32_t)h);
+}
+PT_DEV void get_2d_bits(Sampler& s, const SamplerCtx& c, uint32_t& b0, uint32_t& b1) {   // :215-230
+    uint64_t si = sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits);
+    s.dimension += 2;
+    uint64_t h = dim_hash(c, s.dimension);
+    b0 = fast_owen(sobol_dim0(si), (uint32_t)h);
+    b1 = fast_owen(sobol_dim1(si), (uint32_t)(h >> 32));
+}
+PT_DEV float get_1d(Sampler& s, const SamplerCtx& c) {
+    if (c.mode == 0) return random_next(s);
+    return sobol_bits_to_float(get_1d_bits(s, c));
+}
+PT_DEV f2 get_2d(Sampler& s, const SamplerCtx& c) {
+    if (c.mode == 0) { float a = random_next(s); float b = random_next(s); return f2{a, b}; }
+    uint32_t b0, b1; get_2d_bits(s, c, b0, b1);
+    return f2{sobol_bits_to_float(b0), sobol_bits_to_float(b1)};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Spectra
+// ---------------------------------------------------------------------------------------------
+struct Wl {                 // SampledWavelengths (sampled_spectrum.rs:304-366)
+    float lam[4];
+    bool term;              // secondary wavelengths terminated: pdf = {(1/470)/4, 0, 0, 0}
+};
+PT_DEV void wl_init(Wl& w, float u) {
+    w.lam[0] = LAMBDA_MIN + u * (LAMBDA_MAX - LAMBDA_MIN);
+    const float delta = (LAMBDA_MAX - LAMBDA_MIN) / 4.0f;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        float l = w.lam[i - 1] + delta;
+        if (l >= LAMBDA_MAX) l = LAMBDA_MIN + (l - LAMBDA_MAX);
+        w.lam[i] = l;
+    }
+    w.term = false;
+}
+PT_DEV float srgb_eotf_inverse(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
+PT_DEV float lut_value(const float* lut, float lambda) {                 // densely_sampled_spectrum.rs:57-67
+    if (!(lambda >= LAMBDA_MIN && lambda <= LAMBDA_MAX)) return 0.0f;
+    int idx = (int)floorf(lambda - LAMBDA_MIN);
+    return idx < 470 ? lut[idx] : 0.0f;
+}
+PT_DEV float sigmoid_value(float c0, float c1, float c2, float lambda) {   // rgb_sigmoid_polynomial.rs:17-23,179-182
+    float t = (lambda - LAMBDA_MIN) / (LAMBDA_MAX - LAMBDA_MIN);
+    float x = t * t * c0 + t * c1 + c2;
+    return 1.0f / (1.0f + expf(-x));
+}
+PT_DEV void fetch_texel(const DevScene& sc, const DevTexture& t, uint32_t x, uint32_t y, float out[3]) {
+    uint32_t v = sc.texels[t.offset + y * t.w + x];
+    out[0] = (float)(v & 255u) / 255.0f; out[1] = (float)((v >> 8) & 255u) / 255.0f; out[2] = (float)((v >> 16) & 255u) / 255.0f;
+}
+PT_DEV void bilinear_rgb(const DevScene& sc, uint32_t tex, f2 uv, float out[3]) {   // texture/sampler.rs:6-45
+    DevTexture t = sc.textures[tex];
+    float u = fabsf(uv.x - truncf(uv.x));
+    float v = 1.0f - fabsf(uv.y - truncf(uv.y));
+    float x = u * ((float)t.w - 1.0f), y = v * ((float)t.h - 1.0f);
+    uint32_t x0 = (uint32_t)floorf(x), y0 = (uint32_t)floorf(y);
+    uint32_t x1 = min(x0 + 1u, t.w - 1u), y1 = min(y0 + 1u, t.h - 1u);
+    float fx = x - (float)x0, fy = y - (float)y0;
+    float p00[3], p10[3], p01[3], p11[3];
+    fetch_texel(sc, t, x0, y0, p00); fetch_texel(sc, t, x1, y0, p10);
+    fetch_texel(sc, t, x0, y1, p01); fetch_texel(sc, t, x1, y1, p11);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float top = p00[c] * (1.0f - fx) + p10[c] * fx;
+        float bottom = p01[c] * (1.0f - fx) + p11[c] * fx;
+        out[c] = top * (1.0f - fy) + bottom * fy;
+    }
+}
+// RgbToSpectrumTable::get for gamma-encoded sRGB input (rgb_sigmoid_polynomial.rs:87-155); table repacked to float4 cells.
+PT_DEV void rgb2spec_lookup(const DevScene& sc, const float enc[3], float c[3]) {
+    float rgb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rgb[i] = fmaxf(srgb_eotf_inverse(enc[i]), 0.0f);
+    if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) { c[0] = 0.0f; c[1] = 0.0f; c[2] = logf(rgb[0] / (1.0f - rgb[0])); return; }
+    int mc = 0; float mx = rgb[0];
+    if (rgb[1] > mx) { mx = rgb[1]; mc = 1; }
+    if (rgb[2] > mx) { mc = 2; }
+    float z = mc == 0 ? rgb[0] : (mc == 1 ? rgb[1] : rgb[2]);
+    float r1 = mc == 0 ? rgb[1] : (mc == 1 ? rgb[2] : rgb[0]);
+    float r2 = mc == 0 ? rgb[2] : (mc == 1 ? rgb[0] : rgb[1]);
+    float x = r1 * 63.0f / z, y = r2 * 63.0f / z;
+    int xi = min((int)x, 62), yi = min((int)y, 62);
+    // first i in [0,62] with z_nodes[i+1] > z (else 62): the nodes increase monotonically -> binary search
+    int lo = 0, hi = 62;
+    if (!(sc.z_nodes[63] > z)) lo = 62;
+    else {
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (sc.z_nodes[mid + 1] > z) hi = mid; else lo = mid + 1; }
+    }
+    int zi = lo;
+    float zn0 = sc.z_nodes[zi], zn1 = sc.z_nodes[zi + 1];
+    float dx = x - (float)xi, dy = y - (float)yi, dz = (z - zn0) / (zn1 - zn0);
+    const float4* tab = (const float4*)sc.rgb2spec;
+    size_t base = (((size_t)mc * 64 + zi) * 64 + yi) * 64 + xi;
+    float4 c000 = tab[base], c100 = tab[base + 1], c010 = tab[base + 64], c110 = tab[base + 65];
+    float4 c001 = tab[base + 4096], c101 = tab[base + 4097], c011 = tab[base + 4160], c111 = tab[base + 4161];
+#define PT_LERP(a, b, t) ((a) + ((b) - (a)) * (t))
+#define PT_TRI(m) PT_LERP(PT_LERP(PT_LERP(c000.m, c100.m, dx), PT_LERP(c010.m, c110.m, dx), dy), \
+                          PT_LERP(PT_LERP(c001.m, c101.m, dx), PT_LERP(c011.m, c111.m, dx), dy), dz)
+    c[0] = PT_TRI(x); c[1] = PT_TRI(y); c[2] = PT_TRI(z);
+#undef PT_TRI
+#undef PT_LERP
+}
+
+struct StatCounters {
+    uint32_t closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow, closest_hits, bounces, spectrum_evals,
+        textured_lookups, samples;
+};
+
+// SpectrumParameter::sample(uv).sample(lambda)  (parameter.rs:38-47, spectrum.rs:32-46)
+template <bool STATS>
+PT_DEV void eval_spectrum(const DevScene& sc, const DevSpectrum& sp, const Wl& w, f2 uv, float out[4], StatCounters& st) {
+    if (STATS) st.spectrum_evals++;
+    float c0 = sp.c[0], c1 = sp.c[1], c2 = sp.c[2];
+    uint32_t kind = sp.kind;
+    if (kind == SPK_TEXTURE) {
+        if (STATS) st.textured_lookups++;
+        float rgb[3], c[3];
+        bilinear_rgb(sc, sp.id, uv, rgb);
+        rgb2spec_lookup(sc, rgb, c);
+        c0 = c[0]; c1 = c[1]; c2 = c[2];
+        kind = SPK_SIGMOID;
+    }
+    const float* lut = sc.luts + (size_t)sp.id * 470;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v;
+        if (kind == SPK_CONSTANT) v = c0;
+        else if (kind == SPK_SIGMOID) v = sigmoid_value(c0, c1, c2, w.lam[i]);
+        else v = lut_value(lut, w.lam[i]);
+        out[i] = (i > 0 && w.term) ? 0.0f : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Geometry: watertight ray/triangle (math/src/ray.rs:44-182) and BVH2 traversal with LDS stacks.
+// ---------------------------------------------------------------------------------------------
+struct TriVerts { f3 p0, p1, p2; };
+PT_DEV TriVerts load_tri(const DevTri* tris, uint32_t i) {
+    const float4* q = (const float4*)(tris + i);
+    float4 a = q[0], b = q[1], c = q[2];
+    return TriVerts{mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x)};
+}
+
+// returns true and (t, b0, b1, b2) when the ray hits within (0, t_max]
+PT_DEV bool intersect_triangle(f3 ro, f3 rd, int kx, int ky, int kz, float sx, float sy, float sz, float t_max, const TriVerts& tv,
+                               float& t_out, float& b0o, float& b1o, float& b2o) {
+    f3 c = cross(tv.p1 - tv.p0, tv.p2 - tv.p0);
+    if (dot(c, c) == 0.0f) return false;                                   // degenerate (:49-56)
+    f3 a0 = tv.p0 - ro, a1 = tv.p1 - ro, a2 = tv.p2 - ro;
+    float p0x = comp(a0, kx), p0y = comp(a0, ky), p0z = comp(a0, kz);
+    float p1x = comp(a1, kx), p1y = comp(a1, ky), p1z = comp(a1, kz);
+    float p2x = comp(a2, kx), p2y = comp(a2, ky), p2z = comp(a2, kz);
+    p0x += sx * p0z; p0y += sy * p0z;
+    p1x += sx * p1z; p1y += sy * p1z;
+    p2x += sx * p2z; p2y += sy * p2z;
+    float e0 = p2x * p1y - p2y * p1x;
+    float e1 = p0x * p2y - p0y * p2x;
+    float e2 = p1x * p0y - p1y * p0x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {                         // f64 fallback (:91-101)
+        e0 = (float)((double)p2x * (double)p1y - (double)p2y * (double)p1x);
+        e1 = (float)((double)p0x * (double)p2y - (double)p0y * (double)p2x);
+        e2 = (float)((double)p1x * (double)p0y - (double)p1y * (double)p0x);
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.0f) return false;
+    p0z *= sz; p1z *= sz; p2z *= sz;
+    float t_scaled = e0 * p0z + e1 * p1z + e2 * p2z;
+    if (det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) return false;
+    if (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)) return false;
+    float inv_det = 1.0f / det;
+    float t_hit = t_scaled * inv_det;
+    // conservative t > 0 (:137-158); gamma(n) = n*eps/(1-n*eps), eps = 2^-24
+    constexpr float EPSH = 1.1920929e-7f * 0.5f;
+    constexpr float G2 = (2.0f * EPSH) / (1.0f - 2.0f * EPSH), G3 = (3.0f * EPSH) / (1.0f - 3.0f * EPSH),
+                    G5 = (5.0f * EPSH) / (1.0f - 5.0f * EPSH);
+    float max_zt = max3f(fabsf(p0z), fabsf(p1z), fabsf(p2z));
+    float delta_z = G3 * max_zt;
+    float max_xt = max3f(fabsf(p0x), fabsf(p1x), fabsf(p2x));
+    float max_yt = max3f(fabsf(p0y), fabsf(p1y), fabsf(p2y));
+    float delta_x = G5 * max_xt, delta_y = G5 * max_yt;
+    float delta_e = 2.0f * (G2 * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
+    float max_e = max3f(fabsf(e0), fabsf(e1), fabsf(e2));
+    float delta_t = 3.0f * (G3 * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
+    if (t_hit < delta_t) return false;
+    t_out = t_hit; b0o = e0 * inv_det; b1o = e1 * inv_det; b2o = e2 * inv_det;
+    return true;
+}
+
+struct RaySetup { int kx, ky, kz; float sx, sy, sz; f3 inv; };
+PT_DEV RaySetup setup_ray(f3 rd) {
+    RaySetup r;
+    float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
+    int kz = 0; float m = ax;                                              // glam max_position: first maximum
+    if (ay > m) { m = ay; kz = 1; }
+    if (az > m) { kz = 2; }
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    float dx = comp(rd, kx), dy = comp(rd, ky), dz = comp(rd, kz);
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.sx = -dx / dz; r.sy = -dy / dz; r.sz = 1.0f / dz;
+    r.inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    return r;
+}
+
+struct Hit { float t, b0, b1, b2; uint32_t tri; };
+
+// Closest hit (Scene::intersect, scene.rs:80-90).  One flat BVH2; the far child goes to this lane's LDS stack
+// (stack[depth*64 + lane]: consecutive lanes hit consecutive banks, no conflicts); t_best prunes both
+// boxes and triangles, ties keep the first triangle found.
+template <bool STATS>
+PT_DEV bool trace_closest(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* stack, Hit& hit, StatCounters& st) {
+    RaySetup rs = setup_ray(rd);
+    float t_best = t_max;
+    bool found = false;
+    int sp = 0;
+    int32_t cur = sc.root;
+    if (STATS) st.closest_rays++;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* q = (const float4*)(sc.nodes + cur);
+            float4 nx = q[0], ny = q[1], nz = q[2];
+            int2 ch = *(const int2*)(q + 3);
+            if (STATS) st.nodes_closest++;
+            float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
+            float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
+            float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
+            float l1y = (ny.y - ro.y) * rs.inv.y, h1y = (ny.w - ro.y) * rs.inv.y;
+            float l0z = (nz.x - ro.z) * rs.inv.z, h0z = (nz.z - ro.z) * rs.inv.z;
+            float l1z = (nz.y - ro.z) * rs.inv.z, h1z = (nz.w - ro.z) * rs.inv.z;
+            float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+            float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_best));
+            float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+            float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_best));
+            bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+            if (hit0 && hit1) {
+                bool first0 = n0 <= n1;
+                int32_t nearc = first0 ? ch.x : ch.y, farc = first0 ? ch.y : ch.x;
+                stack[sp * 64] = (uint32_t)farc; ++sp;
+                cur = nearc;
+                continue;
+            } else if (hit0) { cur = ch.x; continue; }
+            else if (hit1) { cur = ch.y; continue; }
+        } else {
+            uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+            for (uint32_t i = 0; i < cnt; ++i) {
+                TriVerts tv = load_tri(sc.tris, first + i);
+                float t, b0, b1, b2;
+                if (STATS) st.tris_closest++;
+                if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
+                    if (!found || t < t_best) { found = true; t_best = t; hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = first + i; }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = (int32_t)stack[sp * 64];
+    }
+    if (STATS && found) st.closest_hits++;
+    return found;
+}
+
+// Any hit within (0, t_max] (Scene::intersect_p, scene.rs:93-103)
+template <bool STATS>
+PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* stack, StatCounters& st) {
+    RaySetup rs = setup_ray(rd);
+    int sp = 0;
+    int32_t cur = sc.root;
+    if (STATS) st.shadow_rays++;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* q = (const float4*)(sc.nodes + cur);
+            float4 nx = q[0], ny = q[1], nz = q[2];
+            int2 ch = *(const int2*)(q + 3);
+            if (STATS) st.nodes_shadow++;
+            float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
+            float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
+            float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
+            float l1y = (ny.y - ro.y) * rs.inv.y, h1y = (ny.w - ro.y) * rs.inv.y;
+            float l0z = (nz.x - ro.z) * rs.inv.z, h0z = (nz.z - ro.z) * rs.inv.z;
+            float l1z = (nz.y - ro.z) * rs.inv.z, h1z = (nz.w - ro.z) * rs.inv.z;
+            float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+            float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_max));
+            float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+            float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_max));
+            bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+            if (hit0 && hit1) { stack[sp * 64] = (uint32_t)ch.y; ++sp; cur = ch.x; continue; }
+            else if (hit0) { cur = ch.x; continue; }
+            else if (hit1) { cur = ch.y; continue; }
+        } else {
+            uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+            for (uint32_t i = 0; i < cnt; ++i) {
+                TriVerts tv = load_tri(sc.tris, first + i);
+                float t, b0, b1, b2;
+                if (STATS) st.tris_shadow++;
+                if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_max, tv, t, b0, b1, b2)) return true;
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = (int32_t)stack[sp * 64];
+    }
+    return false;
+}
+
+}  // namespace pt

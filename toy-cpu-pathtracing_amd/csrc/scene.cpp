@@ -1,0 +1,270 @@
+// Scene lowering: C-ABI description -> flat HBM layout (layout.hpp).  Host-only C++ (compiled by hipcc).
+#include "scene.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+namespace pt {
+
+namespace {
+
+struct V3 { float x, y, z; };
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+inline float length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalize(V3 a) { float r = 1.0f / length(a); return {a.x * r, a.y * r, a.z * r}; }
+
+// column-major 4x4 * point (same operation order as glam::Mat4::transform_point3 so that light triangles
+// and BVH triangles land on the very floats the reference computes in EmissiveTriangleMesh::sample_radiance)
+inline V3 xform_point(const float* m, V3 p) {
+    float r[4];
+    for (int i = 0; i < 4; ++i) r[i] = m[i] * p.x;
+    for (int i = 0; i < 4; ++i) r[i] = r[i] + m[4 + i] * p.y;
+    for (int i = 0; i < 4; ++i) r[i] = r[i] + m[8 + i] * p.z;
+    for (int i = 0; i < 4; ++i) r[i] = r[i] + m[12 + i];
+    return {r[0], r[1], r[2]};
+}
+inline void mat4_mul(const float* a, const float* b, float* o) {   // o = a * b, column-major
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float s = a[r] * b[4 * c];
+            s = s + a[4 + r] * b[4 * c + 1];
+            s = s + a[8 + r] * b[4 * c + 2];
+            s = s + a[12 + r] * b[4 * c + 3];
+            o[4 * c + r] = s;
+        }
+}
+inline bool mat3_inverse_transpose(const float* m /*col-major 3x3*/, float* o, float* det_out) {
+    double a = m[0], b = m[3], c = m[6], d = m[1], e = m[4], f = m[7], g = m[2], h = m[5], i = m[8];
+    double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    *det_out = (float)det;
+    if (det == 0.0) return false;
+    double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                     (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                     (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};   // row-major inverse
+    // inverse-transpose, column-major: o[col*3+row] = inv[col][row] (row-major inv) => element (row,col) of inv^T = inv[col][row]
+    for (int col = 0; col < 3; ++col) for (int row = 0; row < 3; ++row) o[col * 3 + row] = (float)inv[col * 3 + row];
+    return true;
+}
+
+template <typename T>
+int upload(SceneImpl* s, const std::vector<T>& v, const T** out, std::string* err) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { *err = std::string("hipMalloc: ") + hipGetErrorString(e); return MI355PT_E_DEVICE; }
+    s->allocs.push_back(p);
+    if (!v.empty()) {
+        e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { *err = std::string("hipMemcpy: ") + hipGetErrorString(e); return MI355PT_E_DEVICE; }
+    }
+    *out = (const T*)p;
+    return MI355PT_OK;
+}
+
+}  // namespace
+
+SceneImpl::~SceneImpl() { release(); }
+void SceneImpl::release() {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    built = false;
+}
+
+static inline float srgb_eotf_inverse(float c) { return c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f); }
+
+bool SceneImpl::table_lookup_srgb(const float enc[3], float c[3]) const {
+    const int TBL = 64;
+    if (table.size() != (size_t)(TBL + 3 * TBL * TBL * TBL * 3)) return false;
+    float rgb[3];
+    for (int i = 0; i < 3; ++i) rgb[i] = std::fmax(srgb_eotf_inverse(enc[i]), 0.0f);
+    if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) { c[0] = 0; c[1] = 0; c[2] = std::log(rgb[0] / (1.0f - rgb[0])); return true; }
+    int mc = 0; float mx = rgb[0];
+    if (rgb[1] > mx) { mx = rgb[1]; mc = 1; }
+    if (rgb[2] > mx) { mc = 2; }
+    float z = rgb[mc];
+    float x = rgb[(mc + 1) % 3] * 63.0f / z, y = rgb[(mc + 2) % 3] * 63.0f / z;
+    int xi = std::min((int)x, TBL - 2), yi = std::min((int)y, TBL - 2), zi = TBL - 2;
+    for (int i = 0; i <= TBL - 2; ++i) if (table[i + 1] > z) { zi = i; break; }
+    float dx = x - (float)xi, dy = y - (float)yi, dz = (z - table[zi]) / (table[zi + 1] - table[zi]);
+    auto co = [&](int ddx, int ddy, int ddz, int k) {
+        return table[TBL + ((((size_t)mc * TBL + zi + ddz) * TBL + yi + ddy) * TBL + xi + ddx) * 3 + k];
+    };
+    auto lerp = [](float a, float b, float t) { return a + (b - a) * t; };
+    for (int k = 0; k < 3; ++k)
+        c[k] = lerp(lerp(lerp(co(0, 0, 0, k), co(1, 0, 0, k), dx), lerp(co(0, 1, 0, k), co(1, 1, 0, k), dx), dy),
+                    lerp(lerp(co(0, 0, 1, k), co(1, 0, 1, k), dx), lerp(co(0, 1, 1, k), co(1, 1, 1, k), dx), dy), dz);
+    return true;
+}
+
+int SceneImpl::lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, bool allow_texture, std::string* err) const {
+    std::memset(out, 0, sizeof(*out));
+    switch (in.kind) {
+        case MI355PT_SPEC_CONSTANT: out->kind = SPK_CONSTANT; out->c[0] = in.c[0]; return MI355PT_OK;
+        case MI355PT_SPEC_SIGMOID: out->kind = SPK_SIGMOID; std::memcpy(out->c, in.c, 12); return MI355PT_OK;
+        case MI355PT_SPEC_RGB_ALBEDO_SRGB:
+            if (!table_lookup_srgb(in.c, out->c)) { *err = "RGB spectrum needs mi355pt_scene_set_rgb2spec first"; return MI355PT_E_INVALID; }
+            out->kind = SPK_SIGMOID; return MI355PT_OK;
+        case MI355PT_SPEC_LUT470:
+            if (in.id >= luts.size()) { *err = "bad LUT id"; return MI355PT_E_INVALID; }
+            out->kind = SPK_LUT; out->id = in.id; return MI355PT_OK;
+        case MI355PT_SPEC_TEXTURE_ALBEDO_SRGB:
+            if (!allow_texture) { *err = "texture spectrum not supported for this parameter"; return MI355PT_E_INVALID; }
+            if (in.id >= textures.size() || table.empty()) { *err = "bad texture id or missing rgb2spec table"; return MI355PT_E_INVALID; }
+            out->kind = SPK_TEXTURE; out->id = in.id; return MI355PT_OK;
+        default: *err = "unknown spectrum kind"; return MI355PT_E_INVALID;
+    }
+}
+
+int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std::string* err) {
+    release();
+    if (instances.empty()) { *err = "scene has no instances"; return MI355PT_E_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { *err = "no HIP device: the product path requires a gfx950 GPU"; return MI355PT_E_NO_DEVICE; }
+    (void)hipGetDevice(&device);
+
+    // world -> render = translate(-camera position)  (camera.rs:84-86, scene.rs:65-66)
+    float w2r[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -cam->position[0], -cam->position[1], -cam->position[2], 1};
+
+    std::vector<DevInstance> dinst(instances.size());
+    std::vector<DevTri> tris_unordered;
+    std::vector<DevTriShade> shade_unordered;
+    std::vector<BuildTri> btris;
+    std::vector<DevLight> lights;
+    std::vector<DevLightTri> light_tris;
+
+    for (size_t ii = 0; ii < instances.size(); ++ii) {
+        const HostInstance& inst = instances[ii];
+        const HostMesh& mesh = meshes[inst.geom];
+        const DevMaterial& mat = materials[inst.mat];
+        float l2r[16];
+        mat4_mul(w2r, inst.l2w, l2r);                                          // triangle_mesh.rs:38-40
+        DevInstance& di = dinst[ii];
+        di.lin[0] = l2r[0]; di.lin[1] = l2r[1]; di.lin[2] = l2r[2];
+        di.lin[3] = l2r[4]; di.lin[4] = l2r[5]; di.lin[5] = l2r[6];
+        di.lin[6] = l2r[8]; di.lin[7] = l2r[9]; di.lin[8] = l2r[10];
+        float det;
+        if (!mat3_inverse_transpose(di.lin, di.nrm, &det)) { *err = "singular instance transform"; return MI355PT_E_INVALID; }
+        const float idm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        di.identity = std::memcmp(di.lin, idm, sizeof(idm)) == 0 ? 1u : 0u;
+        di.pad = 0;
+        bool emissive = mat.type == MT_EMISSIVE;
+        uint32_t light_index = ~0u;
+        std::vector<float> area_list, area_table;
+        float area_sum = 0.0f;
+        if (emissive) {
+            // EmissiveTriangleMesh::new: areas in WORLD space (emissive_triangle_mesh.rs:28-68)
+            for (uint32_t t = 0; t < mesh.n_tri; ++t) {
+                V3 p[3];
+                for (int k = 0; k < 3; ++k) { uint32_t v = mesh.idx[3 * t + k]; p[k] = xform_point(inst.l2w, V3{mesh.pos[3 * v], mesh.pos[3 * v + 1], mesh.pos[3 * v + 2]}); }
+                V3 e0 = p[0] - p[1], e1 = p[0] - p[2];
+                area_list.push_back(length(cross(e0, e1)) * 0.5f);
+            }
+            for (float a : area_list) { area_sum += a; area_table.push_back(area_sum); }
+            for (float& a : area_table) a /= area_sum;
+            light_index = (uint32_t)lights.size();
+            lights.push_back(DevLight{(uint32_t)light_tris.size(), mesh.n_tri, inst.mat, area_sum});
+        }
+        for (uint32_t t = 0; t < mesh.n_tri; ++t) {
+            V3 p[3];
+            uint32_t vi[3] = {mesh.idx[3 * t], mesh.idx[3 * t + 1], mesh.idx[3 * t + 2]};
+            for (int k = 0; k < 3; ++k) p[k] = xform_point(l2r, V3{mesh.pos[3 * vi[k]], mesh.pos[3 * vi[k] + 1], mesh.pos[3 * vi[k] + 2]});
+            if (det < 0.0f) { std::swap(p[1], p[2]); std::swap(vi[1], vi[2]); }   // keep the geometric normal's orientation
+            DevTri dt{};
+            dt.p0[0] = p[0].x; dt.p0[1] = p[0].y; dt.p0[2] = p[0].z; dt.p1x = p[1].x;
+            dt.p1yz[0] = p[1].y; dt.p1yz[1] = p[1].z; dt.p2xy[0] = p[2].x; dt.p2xy[1] = p[2].y; dt.p2z = p[2].z;
+            tris_unordered.push_back(dt);
+            BuildTri bt;
+            for (int a = 0; a < 3; ++a) {
+                float v0 = (&p[0].x)[a], v1 = (&p[1].x)[a], v2 = (&p[2].x)[a];
+                bt.lo[a] = std::fmin(v0, std::fmin(v1, v2)); bt.hi[a] = std::fmax(v0, std::fmax(v1, v2));
+                bt.c[a] = 0.5f * (bt.lo[a] + bt.hi[a]);
+            }
+            btris.push_back(bt);
+            DevTriShade sh{};
+            const float* n0 = &mesh.nrm[3 * vi[0]]; const float* n1 = &mesh.nrm[3 * vi[1]]; const float* n2 = &mesh.nrm[3 * vi[2]];
+            sh.n0[0] = n0[0]; sh.n0[1] = n0[1]; sh.n0[2] = n0[2]; sh.n1x = n1[0];
+            sh.n1yz[0] = n1[1]; sh.n1yz[1] = n1[2]; sh.n2xy[0] = n2[0]; sh.n2xy[1] = n2[1]; sh.n2z = n2[2];
+            sh.flags = 0;
+            if (!mesh.uv.empty()) {
+                sh.flags |= 1u;
+                sh.tangent[0] = mesh.tangent[3 * t]; sh.tangent[1] = mesh.tangent[3 * t + 1]; sh.tangent[2] = mesh.tangent[3 * t + 2];
+                sh.uv0[0] = mesh.uv[2 * vi[0]]; sh.uv0[1] = mesh.uv[2 * vi[0] + 1];
+                sh.uv1[0] = mesh.uv[2 * vi[1]]; sh.uv1[1] = mesh.uv[2 * vi[1] + 1];
+                sh.uv2[0] = mesh.uv[2 * vi[2]]; sh.uv2[1] = mesh.uv[2 * vi[2] + 1];
+            }
+            sh.material = inst.mat; sh.instance = (uint32_t)ii; sh.local_tri = t; sh.light = light_index;
+            sh.light_pdf_area = 0.0f;
+            if (emissive) {
+                sh.flags |= 2u;
+                float probability = t == 0 ? area_table[0] : area_table[t] - area_table[t - 1];
+                sh.light_pdf_area = 1.0f / area_list[t] * probability;                       // :334-353
+                DevLightTri lt{};
+                // sample_radiance transforms the ORIGINAL vertex order with local_to_render (:200-206)
+                V3 q[3];
+                for (int k = 0; k < 3; ++k) { uint32_t v = mesh.idx[3 * t + k]; q[k] = xform_point(l2r, V3{mesh.pos[3 * v], mesh.pos[3 * v + 1], mesh.pos[3 * v + 2]}); }
+                lt.p0[0] = q[0].x; lt.p0[1] = q[0].y; lt.p0[2] = q[0].z; lt.p1x = q[1].x;
+                lt.p1yz[0] = q[1].y; lt.p1yz[1] = q[1].z; lt.p2xy[0] = q[2].x; lt.p2xy[1] = q[2].y; lt.p2z = q[2].z;
+                lt.cdf = area_table[t];
+                light_tris.push_back(lt);
+            }
+            shade_unordered.push_back(sh);
+        }
+    }
+    if (btris.empty()) { *err = "scene has no triangles"; return MI355PT_E_INVALID; }
+    if (btris.size() >= (1u << 28)) { *err = "too many triangles"; return MI355PT_E_INVALID; }
+
+    BvhOut bvh;
+    build_bvh(btris, &bvh);
+    bvh_depth = bvh.max_depth;
+    if (bvh.max_depth >= STACK_DEPTH) { *err = "BVH deeper than the traversal stack"; return MI355PT_E_INVALID; }
+    std::vector<DevTri> tris(bvh.order.size());
+    std::vector<DevTriShade> shade(bvh.order.size());
+    for (size_t i = 0; i < bvh.order.size(); ++i) { tris[i] = tris_unordered[bvh.order[i]]; shade[i] = shade_unordered[bvh.order[i]]; }
+
+    // LUT pool, CMF, table (repacked to float4 cells), textures (RGBA8)
+    std::vector<float> lut_pool;
+    for (auto& l : luts) lut_pool.insert(lut_pool.end(), l.begin(), l.end());
+    std::vector<float> cmf(cmf4, cmf4 + 470 * 4);
+    std::vector<float> tab4, znodes;
+    if (!table.empty()) {
+        const size_t cells = (size_t)3 * 64 * 64 * 64;
+        tab4.resize(cells * 4);
+        for (size_t c = 0; c < cells; ++c) { tab4[4 * c] = table[64 + 3 * c]; tab4[4 * c + 1] = table[64 + 3 * c + 1]; tab4[4 * c + 2] = table[64 + 3 * c + 2]; tab4[4 * c + 3] = 0.0f; }
+        znodes.assign(table.begin(), table.begin() + 64);
+    }
+    std::vector<uint32_t> texels;
+    std::vector<DevTexture> dtex;
+    for (auto& t : textures) {
+        dtex.push_back(DevTexture{(uint32_t)texels.size(), t.w, t.h, 0});
+        size_t n = (size_t)t.w * t.h;
+        for (size_t i = 0; i < n; ++i) texels.push_back((uint32_t)t.rgb[3 * i] | ((uint32_t)t.rgb[3 * i + 1] << 8) | ((uint32_t)t.rgb[3 * i + 2] << 16));
+    }
+
+    int rc;
+    std::memset(&dev, 0, sizeof(dev));
+    if ((rc = upload(this, bvh.nodes, &dev.nodes, err))) return rc;
+    if ((rc = upload(this, tris, &dev.tris, err))) return rc;
+    if ((rc = upload(this, shade, &dev.shade, err))) return rc;
+    if ((rc = upload(this, dinst, &dev.instances, err))) return rc;
+    if ((rc = upload(this, materials, &dev.materials, err))) return rc;
+    if ((rc = upload(this, lights, &dev.lights, err))) return rc;
+    if ((rc = upload(this, light_tris, &dev.light_tris, err))) return rc;
+    if ((rc = upload(this, lut_pool, &dev.luts, err))) return rc;
+    if ((rc = upload(this, cmf, &dev.cmf, err))) return rc;
+    if ((rc = upload(this, tab4, &dev.rgb2spec, err))) return rc;
+    if ((rc = upload(this, znodes, &dev.z_nodes, err))) return rc;
+    if ((rc = upload(this, texels, &dev.texels, err))) return rc;
+    if ((rc = upload(this, dtex, &dev.textures, err))) return rc;
+    dev.n_nodes = (uint32_t)bvh.nodes.size(); dev.n_tris = (uint32_t)tris.size();
+    dev.n_lights = (uint32_t)lights.size(); dev.n_materials = (uint32_t)materials.size();
+    dev.root = bvh.root;
+    info = "nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth);
+    built = true;
+    return MI355PT_OK;
+}
+
+}  // namespace pt

@@ -1,0 +1,66 @@
+// Host-side scene: stores what the C ABI hands over, lowers it to the flat HBM layout of layout.hpp
+// (single render-space BVH over all instances, leaf-ordered triangles, per-triangle shading records,
+// light tables) and owns the device buffers.  Replaces Scene::build (scene/src/scene.rs:64-76).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/mi355pt.h"
+#include "layout.hpp"
+
+namespace pt {
+
+struct HostMesh {
+    std::vector<float> pos, nrm, uv, tangent;   // nrm normalised twice like Normal::new (normal.rs:18-20,93-100)
+    std::vector<uint32_t> idx;
+    uint32_t n_vert = 0, n_tri = 0;
+};
+struct HostInstance { uint32_t geom, mat; float l2w[16]; };
+
+struct BuildTri { float lo[3], hi[3], c[3]; };
+struct BvhOut {
+    std::vector<DevNode> nodes;
+    std::vector<uint32_t> order;   // leaf-ordered triangle permutation
+    int32_t root = 0;
+    int max_depth = 0;
+};
+// Sweep-SAH BVH2 over triangle bounds; children boxes stored in the parent (layout.hpp DevNode).
+void build_bvh(const std::vector<BuildTri>& tris, BvhOut* out);
+
+struct DeviceBuffers {
+    void* ptrs[16] = {nullptr};
+    int n = 0;
+};
+
+struct SceneImpl {
+    // ---- description ----
+    std::vector<float> table;                 // reference layout [64][3][64][64][64][3]
+    std::vector<std::vector<float>> luts;
+    struct Tex { std::vector<uint8_t> rgb; uint32_t w, h; };
+    std::vector<Tex> textures;
+    std::vector<HostMesh> meshes;
+    std::vector<mi355pt_material_desc> mat_descs;
+    std::vector<DevMaterial> materials;
+    std::vector<HostInstance> instances;
+    // ---- lowered ----
+    bool built = false;
+    int device = -1;
+    DevScene dev{};
+    std::vector<void*> allocs;
+    uint32_t cmf_lut[3] = {0, 0, 0};
+    int bvh_depth = 0;
+    std::string info;
+
+    ~SceneImpl();
+    void release();
+    // RgbSigmoidPolynomial::from(ColorSrgb) on the host (rgb_sigmoid_polynomial.rs:87-155)
+    bool table_lookup_srgb(const float rgb_encoded[3], float c[3]) const;
+    int lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, bool allow_texture, std::string* err) const;
+    int build(const mi355pt_camera* cam, const float* cmf_xyz /*3*470*/, std::string* err);
+};
+
+// baked CIE 1931 colour matching functions shipped with the library (data/presets470.bin rows cie_x/y/z)
+const float* builtin_cmf_xyz();   // 3*470 floats or nullptr if not loaded
+bool load_builtin_cmf(std::string* err);
+
+}  // namespace pt
