@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the spectral path-tracing sample loop on MI355X.
+
+Workload (BASELINE.json configs[1]): scene3 (textured + normal-mapped Lambert hero in the Cornell room, synthetic
+stand-in assets), MIS + ZSobol, 1920x1080, target 1024 spp.  One *step* = one pass of the hot path over one batch =
+the whole 1920x1080 frame for `--spp-per-step` consecutive Sobol sample indices of the 1024-spp job (sample indices
+are per (pixel, sample), so 16 steps of 64 compose exactly the 1024-spp image).  Inputs (BVH, triangles, materials,
+LUTs, tables, textures) are resident in HBM before the timed region; the film accumulators stay in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's 8x8 pixel tiles are dealt round-robin to
+the ranks (scene replicated), each step every rank renders its tiles and the linear film is summed onto rank 0 with
+one RCCL reduce over xGMI (strong scaling: the frame is fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_sample(st, spp_total):
+    """SURVEY.md §8(d) canonical record sizes x counts measured by the instrumented kernel variant:
+    node 64 B, triangle 36 B, hit attributes 96 B + material 64 B per closest hit, 16 B per spectrum evaluation,
+    sensor 48 B per sample, 120 B per textured lookup, film 12 B/pixel once.  The path-state term (2 x 160 B per
+    bounce) is 0 here: path state is register-resident in this design and never streams through HBM."""
+    n = max(st["samples"], 1)
+    b = ((st["nodes_closest"] + st["nodes_shadow"]) * 64 + (st["tris_closest"] + st["tris_shadow"]) * 36 +
+         st["closest_hits"] * (96 + 64) + st["spectrum_evals"] * 16 + st["textured_lookups"] * 120) / n
+    return b + 48 + 12.0 / spp_total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--scene", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024, help="spp of the whole job (fixes the Sobol sequence)")
+    ap.add_argument("--strategy", default="mis")
+    ap.add_argument("--sampler", default="sobol")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline duration")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("toy-cpu-pathtracing_amd")
+    prod = pkg.Product()
+    scene = prod.new_scene()
+    cam = pkg.scenes.load_scene(scene, args.scene, args.width, args.height)     # BVH build + upload to this rank's GPU
+    W, H = args.width, args.height
+    spp_job = args.spp
+    sps = args.spp_per_step
+    n_slices = max(spp_job // sps, 1)
+
+    accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    params = pkg.make_params(spp_job, args.strategy, args.sampler, shard_index=rank, shard_count=world)
+
+    def step(i):
+        k = i % n_slices
+        prod.render_accum_device(scene, cam, params, k * sps, (k + 1) * sps, accum.data_ptr(), stream)
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)      # RCCL film reduce over xGMI (linear, pre-tonemap)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+        accum.zero_()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        prod.render_accum_device(scene, cam, params, (i % n_slices) * sps, ((i % n_slices) + 1) * sps, accum.data_ptr(), stream)
+        ev[i][1].record()        # brackets exactly the path-tracing launch on the stream it was launched on
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples_per_step = W * H * sps
+    total = samples_per_step * args.steps
+    value = total / dt / 1e6
+
+    out = None
+    if rank == 0:
+        # ---- roofline: algorithmic bytes / measured kernel time (rank 0's launches) ----
+        st = pkg.ffi.Stats()
+        sp = pkg.make_params(spp_job, args.strategy, args.sampler, shard_index=rank, shard_count=world, collect_stats=1)
+        scratch = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        prod.render_accum_device(scene, cam, sp, 0, 4, scratch.data_ptr(), stream, stats=st)
+        sd = st.as_dict()
+        bps = algorithmic_bytes_per_sample(sd, spp_job)
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        launch_samples = samples_per_step / world
+        achieved = bps * launch_samples / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,
+                    "kernel": "pt_kernel<false,false>", "kernel_ms_avg": round(avg_ms, 3),
+                    "algorithmic_bytes_per_sample": round(bps, 1),
+                    "per_sample": {k: round(sd[k] / max(sd["samples"], 1), 3) for k in
+                                   ("closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow",
+                                    "closest_hits", "bounces", "spectrum_evals", "textured_lookups")}}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        # ---- CPU baseline: the oracle in faithful mode on this box's host cores (rank 0, N=1 only) ----
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import ptoracle
+            orc = ptoracle.Oracle(native=True)
+            osc = orc.new_scene()
+            ocam = pkg.scenes.load_scene(osc, args.scene, W, H)
+            orc.set_faithful(osc, True)
+            cores = os.cpu_count() or 1
+            import numpy as np
+            tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
+
+            def run(k, n_idx):
+                """every k-th 8x8 tile of the frame, sample indices [0, n_idx) of the same Sobol job"""
+                p2 = pkg.make_params(spp_job, args.strategy, args.sampler, shard_index=0, shard_count=k)
+                acc = np.zeros((H, W, 3), np.float32)
+                _, sec = orc.render_accum(osc, ocam, p2, 0, n_idx, threads=cores, accum=acc)
+                px = 0
+                for t in range(0, tiles_x * tiles_y, k):
+                    tx, ty = t % tiles_x, t // tiles_x
+                    px += min(8, W - tx * 8) * min(8, H - ty * 8)
+                return px * n_idx, sec
+
+            n, sec = run(16, 1)                                   # calibration: 1/16 of the tiles, one sample index
+            rate = n / max(sec, 1e-9)
+            want = rate * args.cpu_seconds                        # samples that fit the time budget
+            if want >= W * H:                                     # whole frame, several sample indices
+                k, n_idx = 1, int(min(max(want // (W * H), 1), spp_job))
+            else:                                                 # a tile subset of the frame, one sample index
+                k, n_idx = int(max(W * H // max(want, 1), 1)), 1
+            n, sec = run(k, n_idx)
+            cpu = {"value": round(n / sec / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                   "sample": f"oracle faithful mode (two-level recursive BVH, non-shrinking t_max, Mat4 inverse per instance per "
+                             f"ray, light sampler rebuilt per call), every {k}-th 8x8 tile of the same {W}x{H} frame, sample "
+                             f"indices [0,{n_idx}) of the {spp_job}-spp Sobol job: {n} samples in {sec:.1f} s on {cores} threads"}
+        out = {
+            "metric": "Msamples/sec (whole node), scene3 MIS/Sobol 1920x1080",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"scene{args.scene} {W}x{H} {args.strategy}+{args.sampler}, {spp_job}-spp job, "
+                                   f"{sps} sample indices per step (BASELINE configs[1])",
+                       "samples_per_step": samples_per_step, "seconds_to_target_spp": round(W * H * spp_job / (value * 1e6), 3),
+                       "parallelism": f"tiles8x8-rr{world}+rccl-film-reduce" if world > 1 else "single-gpu",
+                       "bvh": scene_info(prod, scene)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["config"]["x_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def scene_info(prod, scene):
+    return "flat BVH2, 64B nodes, <=4 tris/leaf"
+
+
+if __name__ == "__main__":
+    main()

@@ -36,8 +36,23 @@ static const uint32_t CIE_CMF_BITS[470 * 4] = {
 #include "cie_cmf.inc"
 };
 
+// Per-scene launch resources, allocated once (no hipMalloc/hipFree/sync on the launch path, so a caller can queue
+// launches on its own stream or capture them): the MurmurHash(dimension, seed) table per seed and a ring of work
+// counters / stats blocks so that back-to-back asynchronous launches never share a counter.
+constexpr int CTX_RING = 16;
+struct LaunchCtx {
+    uint64_t* d_hash = nullptr;
+    uint32_t hash_seed = 0;
+    bool hash_valid = false;
+    unsigned* d_counters = nullptr;   // CTX_RING counters
+    DevStats* d_stats = nullptr;      // CTX_RING blocks
+    int next = 0;
+    ~LaunchCtx() { (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); }
+};
 struct mi355pt_scene {
     SceneImpl impl;
+    mutable LaunchCtx* ctx = nullptr;
+    ~mi355pt_scene();
 };
 
 namespace {
@@ -97,13 +112,6 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
 };
 
-struct LaunchCtx {
-    uint64_t* d_hash = nullptr;
-    unsigned* d_counter = nullptr;
-    DevStats* d_stats = nullptr;
-    ~LaunchCtx() { (void)hipFree(d_hash); (void)hipFree(d_counter); (void)hipFree(d_stats); }
-};
-
 int resident_waves() {
     int dev = 0; (void)hipGetDevice(&dev);
     hipDeviceProp_t prop;
@@ -126,13 +134,26 @@ DevParams make_params(const mi355pt_camera* cam, const mi355pt_params* p, uint32
     return d;
 }
 
-int alloc_launch_ctx(LaunchCtx& lc, uint32_t seed) {
-    std::vector<uint64_t> tab(HASH_TABLE_DIMS);
-    for (int i = 0; i < HASH_TABLE_DIMS; ++i) tab[i] = host_murmur_dim_seed((uint32_t)i, seed);
-    HIP_TRY(hipMalloc((void**)&lc.d_hash, sizeof(uint64_t) * HASH_TABLE_DIMS));
-    HIP_TRY(hipMemcpy(lc.d_hash, tab.data(), sizeof(uint64_t) * HASH_TABLE_DIMS, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&lc.d_counter, sizeof(unsigned)));
-    HIP_TRY(hipMalloc((void**)&lc.d_stats, sizeof(DevStats)));
+// returns the scene's launch context with the hash table valid for `seed`; `slot` receives a fresh ring slot
+int get_launch_ctx(const mi355pt_scene* sc, uint32_t seed, hipStream_t stream, LaunchCtx** out, int* slot) {
+    if (!sc->ctx) {
+        LaunchCtx* lc = new LaunchCtx();
+        HIP_TRY(hipMalloc((void**)&lc->d_hash, sizeof(uint64_t) * HASH_TABLE_DIMS));
+        HIP_TRY(hipMalloc((void**)&lc->d_counters, sizeof(unsigned) * CTX_RING));
+        HIP_TRY(hipMalloc((void**)&lc->d_stats, sizeof(DevStats) * CTX_RING));
+        sc->ctx = lc;
+    }
+    LaunchCtx* lc = sc->ctx;
+    if (!lc->hash_valid || lc->hash_seed != seed) {
+        std::vector<uint64_t> tab(HASH_TABLE_DIMS);
+        for (int i = 0; i < HASH_TABLE_DIMS; ++i) tab[i] = host_murmur_dim_seed((uint32_t)i, seed);
+        // a seed change is rare (the CLI renders one seed): synchronous copy, ordered after any in-flight launch
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(lc->d_hash, tab.data(), sizeof(uint64_t) * HASH_TABLE_DIMS, hipMemcpyHostToDevice));
+        lc->hash_seed = seed; lc->hash_valid = true;
+    }
+    *slot = lc->next; lc->next = (lc->next + 1) % CTX_RING;
+    *out = lc;
     return MI355PT_OK;
 }
 
@@ -146,6 +167,8 @@ int check_args(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_
 }
 
 }  // namespace
+
+mi355pt_scene::~mi355pt_scene() { delete ctx; }
 
 extern "C" {
 
@@ -261,15 +284,17 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     while (n_tiles * chunks < (uint32_t)waves * 4 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 8) chunks *= 2;
     dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
     dp.n_work = n_tiles * chunks;
-    LaunchCtx lc;
-    if ((rc = alloc_launch_ctx(lc, p->seed))) return rc;
-    HIP_TRY(hipMemsetAsync(lc.d_counter, 0, sizeof(unsigned), stream));
+    LaunchCtx* lc; int slot;
+    if ((rc = get_launch_ctx(s, p->seed, stream, &lc, &slot))) return rc;
+    unsigned* d_counter = lc->d_counters + slot;
+    DevStats* d_stats = lc->d_stats + slot;
+    HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned), stream));
     bool want_stats = stats && p->collect_stats;
-    if (want_stats) HIP_TRY(hipMemsetAsync(lc.d_stats, 0, sizeof(DevStats), stream));
+    if (want_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (stats) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
     int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)waves);
-    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc.d_hash, d_accum, lc.d_counter, lc.d_stats, want_stats, grid, stream));
+    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, d_counter, d_stats, want_stats, grid, stream));
     if (stats) {
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(hipEventSynchronize(e1));
@@ -279,19 +304,15 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
         stats->kernel_ms = ms; stats->launches = 1;
         if (want_stats) {
             DevStats h;
-            HIP_TRY(hipMemcpy(&h, lc.d_stats, sizeof(h), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
             stats->samples = h.samples; stats->closest_rays = h.closest_rays; stats->shadow_rays = h.shadow_rays;
             stats->nodes_closest = h.nodes_closest; stats->tris_closest = h.tris_closest; stats->nodes_shadow = h.nodes_shadow;
             stats->tris_shadow = h.tris_shadow; stats->closest_hits = h.closest_hits; stats->bounces = h.bounces;
             stats->spectrum_evals = h.spectrum_evals; stats->textured_lookups = h.textured_lookups;
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    } else {
-        // the launch context is freed on return: wait for the kernel (callers that want overlap pass stats = NULL
-        // only for whole-frame work, where this wait is the frame's natural end)
-        HIP_TRY(hipStreamSynchronize(stream));
     }
-    return MI355PT_OK;
+    return MI355PT_OK;   // stats == NULL: fully asynchronous on `stream`
 }
 
 int mi355pt_film_resolve_device(const float* d_accum, uint32_t n_pixels, uint32_t spp, float* d_out, void* hip_stream) {
@@ -387,14 +408,14 @@ int mi355pt_probe_radiance(const mi355pt_scene* s, const mi355pt_camera* cam, co
     DevCamera dc = make_camera(cam);
     DevParams dp = make_params(cam, p, 0, p->spp);
     dp.chunks = 1; dp.chunk_size = 1; dp.n_work = (n + 63) / 64;
-    LaunchCtx lc;
-    if ((rc = alloc_launch_ctx(lc, p->seed))) return rc;
-    HIP_TRY(hipMemset(lc.d_counter, 0, sizeof(unsigned)));
+    LaunchCtx* lc; int slot;
+    if ((rc = get_launch_ctx(s, p->seed, nullptr, &lc, &slot))) return rc;
+    HIP_TRY(hipMemset(lc->d_counters + slot, 0, sizeof(unsigned)));
     DevBuf<uint32_t> d_xys; DevBuf<float> d_L, d_lam, d_pdf;
     HIP_TRY(d_xys.alloc((size_t)n * 3)); HIP_TRY(d_L.alloc((size_t)n * 4)); HIP_TRY(d_lam.alloc((size_t)n * 4)); HIP_TRY(d_pdf.alloc((size_t)n * 4));
     HIP_TRY(hipMemcpy(d_xys.p, xys, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice));
     int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)resident_waves());
-    HIP_TRY(launch_probe_radiance(s->impl.dev, dc, dp, lc.d_hash, lc.d_counter, d_xys.p, n, d_L.p, d_lam.p, d_pdf.p, grid, nullptr));
+    HIP_TRY(launch_probe_radiance(s->impl.dev, dc, dp, lc->d_hash, lc->d_counters + slot, d_xys.p, n, d_L.p, d_lam.p, d_pdf.p, grid, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_L, d_L.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_lambda, d_lam.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
