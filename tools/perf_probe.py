@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Quick perf probe used while tuning kernels (GPU box only): Msamples/s of the render launch (HIP events inside the
+library) and the per-phase wave-cycle shares of the instrumented variant."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", type=int, default=3)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--spp", type=int, default=1024)
+ap.add_argument("--slice", type=int, default=32)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--strategy", default="mis")
+ap.add_argument("--sampler", default="sobol")
+ap.add_argument("--tag", default="")
+a = ap.parse_args()
+
+pkg = importlib.import_module("toy-cpu-pathtracing_amd")
+import ctypes as C
+prod = pkg.Product()
+sc = prod.new_scene()
+cam = pkg.scenes.load_scene(sc, a.scene, a.width, a.height)
+hip = C.CDLL("libamdhip64.so")
+n = a.width * a.height * 3 * 4
+d_acc = C.c_void_p()
+assert hip.hipMalloc(C.byref(d_acc), C.c_size_t(n)) == 0
+hip.hipMemset(d_acc, 0, C.c_size_t(n))
+prm = pkg.make_params(a.spp, a.strategy, a.sampler)
+ms = []
+for i in range(a.reps + 1):
+    st = pkg.ffi.Stats()
+    prod.render_accum_device(sc, cam, prm, i * a.slice, (i + 1) * a.slice, d_acc.value, None, stats=st)
+    ms.append(st.kernel_ms)
+best = min(ms[1:])
+rate = a.width * a.height * a.slice / best / 1e3
+prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=1)
+st = pkg.ffi.Stats()
+prod.render_accum_device(sc, cam, prm2, 0, 4, d_acc.value, None, stats=st)
+d = st.as_dict()
+ph = d["phase_cycles"]
+tot = max(ph[5], 1)
+names = ["regen", "closest", "shade", "shadow", "film"]
+print(json.dumps({"tag": a.tag, "scene": a.scene, "Msamples_s": round(rate, 1), "ms": [round(x, 2) for x in ms],
+                  "phase_share": {k: round(v / tot, 3) for k, v in zip(names, ph[:5])},
+                  "per_sample": {k: round(d[k] / max(d["samples"], 1), 2) for k in ("closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow", "bounces")}}))

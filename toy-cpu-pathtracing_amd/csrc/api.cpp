@@ -20,6 +20,7 @@ hipError_t launch_probe_sobol(uint32_t, uint32_t, uint32_t, uint32_t, const uint
 hipError_t launch_probe_intersect(const DevScene&, const float*, const float*, uint32_t, float*, uint32_t*, uint32_t*, float*, hipStream_t);
 hipError_t launch_probe_occluded(const DevScene&, const float*, const float*, const float*, uint32_t, uint8_t*, hipStream_t);
 uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed);
+int query_resident_waves();
 }  // namespace pt
 
 using namespace pt;
@@ -113,10 +114,9 @@ struct DevBuf {
 };
 
 int resident_waves() {
-    int dev = 0; (void)hipGetDevice(&dev);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    return prop.multiProcessorCount * 8;   // 2 waves per SIMD: VGPR-heavy kernel, LDS 9.5 KB per wave
+    static int cached = 0;
+    if (!cached) cached = query_resident_waves();
+    return cached;
 }
 
 DevParams make_params(const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end) {
@@ -309,6 +309,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
             stats->nodes_closest = h.nodes_closest; stats->tris_closest = h.tris_closest; stats->nodes_shadow = h.nodes_shadow;
             stats->tris_shadow = h.tris_shadow; stats->closest_hits = h.closest_hits; stats->bounces = h.bounces;
             stats->spectrum_evals = h.spectrum_evals; stats->textured_lookups = h.textured_lookups;
+            for (int i = 0; i < 6; ++i) stats->phase_cycles[i] = h.phase_cycles[i];
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }

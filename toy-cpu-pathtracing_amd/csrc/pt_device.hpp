@@ -69,9 +69,14 @@ PT_DEV uint32_t part1by1(uint32_t x) {   // 16 low bits -> even bit positions
 PT_DEV uint32_t encode_morton2_u32(uint32_t x, uint32_t y) { return (part1by1(y) << 1) | part1by1(x); }
 
 // The 24 base-4 digit permutations (:102-127), 2 bits per digit packed into a byte.
-__device__ const uint8_t PERM_PACKED[24] = {
-    0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D,
-    0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
+// Kept in three 64-bit immediates and selected arithmetically: a memory table would put 16 dependent loads on the
+// critical path of every Sobol draw.
+//   bytes: E4 B4 D8 78 6C 9C E1 B1 | C9 39 2D 8D C6 36 D2 72 | 4E 1E 27 87 1B 4B 63 93
+PT_DEV uint32_t perm_packed(uint32_t p) {
+    const uint64_t A = 0xB1E19C6C78D8B4E4ull, B = 0x72D236C68D2D39C9ull, C = 0x93634B1B87271E4Eull;
+    uint64_t w = p < 8u ? A : (p < 16u ? B : C);
+    return (uint32_t)(w >> ((p & 7u) * 8u)) & 0xffu;
+}
 
 PT_DEV uint64_t sobol_sample_index(uint32_t morton, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits) {   // :101-156
     uint64_t sample_index = 0;
@@ -85,7 +90,7 @@ PT_DEV uint64_t sobol_sample_index(uint32_t morton, uint32_t dimension, uint32_t
         // (mix >> 24) % 24 on a 40-bit value with 32-bit ops: 2^32 mod 24 == 16
         uint64_t mx = mix_bits(higher ^ dmix) >> 24;
         uint32_t p = (((uint32_t)(mx >> 32) * 16u) + ((uint32_t)mx % 24u)) % 24u;
-        digit = ((uint32_t)PERM_PACKED[p] >> (2u * digit)) & 3u;
+        digit = (perm_packed(p) >> (2u * digit)) & 3u;
         sample_index |= (uint64_t)digit << shift;
     }
     if (pow2) {

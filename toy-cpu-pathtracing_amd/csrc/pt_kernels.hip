@@ -126,8 +126,12 @@ enum : uint32_t { ST_DIFFUSE = 0, ST_SPEC_REFL = 1, ST_SPEC_TRANS = 2, ST_GLOSSY
 
 struct PathOut { float* L; float* lam; float* pdf; };   // probe output (one path per lane)
 
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4   // 128 VGPRs: measured +26 % over the unconstrained 220-VGPR build (latency hiding beats the spills)
+#endif
+
 template <bool STATS, bool PROBE>
-__global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
+__global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, unsigned* __restrict__ work_counter,
                                                 DevStats* __restrict__ stats, const uint32_t* __restrict__ probe_xys, uint32_t n_probe,
                                                 PathOut pout) {
@@ -179,7 +183,12 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
         bool need_new = true;
         bool active = lane_valid && s_cur < s_end;
 
+        unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long t_loop0 = 0;
+        if (STATS) t_loop0 = __builtin_amdgcn_s_memtime();
         while (__any(active)) {
+            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+            if (STATS) ts0 = __builtin_amdgcn_s_memtime();
             if (active && need_new) {
                 // base_renderer.rs:160-177: wavelengths (dim 0), pixel sample (dims 1-2), camera ray
                 sampler_start(smp, sctx, px, py, s_cur);
@@ -200,11 +209,13 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
                 if (STATS) st.samples++;
             }
 
+            if (STATS) ts1 = __builtin_amdgcn_s_memtime();
             // ---------------- extend: closest hit for every active lane ----------------
             Hit hit{};
             bool got = false;
             if (active) got = trace_closest<STATS>(sc, ro, rd, 3.402823466e+38f, stack, hit, st);
 
+            if (STATS) ts2 = __builtin_amdgcn_s_memtime();
             bool end_path = false;
             bool do_shadow = false;
             f3 sh_o = mk3(0, 0, 0), sh_d = mk3(0, 0, 1);
@@ -241,6 +252,15 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
                             else if (prm.strategy == 2u && !prev_spec) {
                                 // Scene::pdf_light_sample (scene.rs:156-182); light probability = phi-weighted pick
                                 float wsum = 0.0f, wme = 0.0f;
+                                if (sc.n_lights == 1u) {
+                                    // one light (every BASELINE config): phi(lambda) is Le * area, already evaluated
+                                    // (emissive radiance cannot be a texture, so Le does not depend on uv)
+                                    float sum = 0.0f;
+                                    float area = sc.lights[0].area_sum;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) sum += Le[i] * area;
+                                    wsum = wme = sum / 4.0f;
+                                } else
                                 for (uint32_t li = 0; li < sc.n_lights; ++li) {
                                     DevLight lt = sc.lights[li];
                                     const DevMaterial* lm = sc.materials + lt.material;
@@ -336,20 +356,32 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
                             if (prm.strategy != 0u) {
                                 // light pick: LightSampler (light_sampler.rs:26-43,190-220)
                                 float ul = get_1d(smp, sctx);
-                                float wsum = 0.0f;
-                                for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                                    DevLight lt = sc.lights[li];
-                                    const DevMaterial* lm = sc.materials + lt.material;
-                                    float ph[4];
-                                    DevSpectrum ls = load_spectrum(&lm->color);
-                                    eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                                    float sum = 0.0f;
+                                // phi-weighted light pick.  The picked light's radiance is evaluated ONCE and doubles as its
+                                // phi weight (emissive radiance is never a texture, so it does not depend on uv).
+                                uint32_t pick = 0; float wsum = 0.0f, wpick = 0.0f;
+                                float lrad[4];
+                                if (sc.n_lights == 1u) {
+                                    const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
+                                    DevSpectrum ls0 = load_spectrum(&lm0->color);
+                                    eval_spectrum<STATS>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
+                                    float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
-                                    wsum += sum / 4.0f;
-                                }
-                                if (sc.n_lights > 0 && wsum != 0.0f) {
-                                    uint32_t pick = sc.n_lights - 1; float cum = 0.0f, wpick = 0.0f; bool chosen = false;
+                                    for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
+                                    wsum = wpick = sum / 4.0f;
+                                } else {
+                                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                                        DevLight lt = sc.lights[li];
+                                        const DevMaterial* lm = sc.materials + lt.material;
+                                        float ph[4];
+                                        DevSpectrum ls = load_spectrum(&lm->color);
+                                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                                        float sum = 0.0f;
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                                        wsum += sum / 4.0f;
+                                    }
+                                    float cum = 0.0f; bool chosen = false;
+                                    pick = sc.n_lights - 1;
                                     for (uint32_t li = 0; li < sc.n_lights; ++li) {
                                         DevLight lt = sc.lights[li];
                                         const DevMaterial* lm = sc.materials + lt.material;
@@ -361,17 +393,24 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
                                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
                                         float wt = sum / 4.0f;
                                         cum += wt;
-                                        if (!chosen && (ul < cum / wsum || li == sc.n_lights - 1)) { chosen = true; pick = li; wpick = wt; }
+                                        if (!chosen && (ul < cum / wsum || li == sc.n_lights - 1)) {
+                                            chosen = true; pick = li; wpick = wt;
+#pragma unroll
+                                            for (int i = 0; i < 4; ++i) lrad[i] = ph[i];
+                                        }
                                     }
+                                }
+                                if (sc.n_lights > 0 && wsum != 0.0f) {
                                     float lprob = wpick / wsum;
                                     float s1 = get_1d(smp, sctx);
                                     f2 luv = get_2d(smp, sctx);
                                     // EmissiveTriangleMesh::sample_radiance (emissive_triangle_mesh.rs:176-308)
                                     DevLight lt = sc.lights[pick];
-                                    uint32_t tsel = 0;
-                                    for (uint32_t k = 0; k < lt.n_tris; ++k) {
-                                        if (s1 < sc.light_tris[lt.first_tri + k].cdf) { tsel = k; break; }
-                                    }
+                                    // first k with s < cdf[k] (else 0, :185-191).  The cdf is non-decreasing, so that index is the
+                                    // number of entries <= s: independent loads instead of a chain of dependent ones.
+                                    uint32_t cnt = 0;
+                                    for (uint32_t k = 0; k < lt.n_tris; ++k) cnt += (s1 < sc.light_tris[lt.first_tri + k].cdf) ? 0u : 1u;
+                                    uint32_t tsel = cnt < lt.n_tris ? cnt : 0u;
                                     const float4* q = (const float4*)(sc.light_tris + lt.first_tri + tsel);
                                     float4 qa = q[0], qb = q[1], qc = q[2];
                                     f3 p0 = mk3(qa.x, qa.y, qa.z), p1 = mk3(qa.w, qb.x, qb.y), p2 = mk3(qb.z, qb.w, qc.x);
@@ -381,9 +420,6 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
                                     f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
                                     f3 ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
                                     const DevMaterial* lm = sc.materials + lt.material;
-                                    float lrad[4];
-                                    DevSpectrum ls = load_spectrum(&lm->color);
-                                    eval_spectrum<STATS>(sc, ls, wl, f2{0.0f, 0.0f}, lrad, st);
                                     float pdf_a = 1.0f / lt.area_sum;
                                     f3 dv = lp - sf.p;
                                     f3 wi_r = normalize(dv);
@@ -488,6 +524,7 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
                 }
             }
 
+            if (STATS) ts3 = __builtin_amdgcn_s_memtime();
             // ---------------- connect: shadow rays of every lane that sampled a light ----------------
             if (do_shadow) {
                 bool occluded = trace_any<STATS>(sc, sh_o, sh_d, sh_t, stack, st);
@@ -497,6 +534,7 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
                 }
             }
 
+            if (STATS) ts4 = __builtin_amdgcn_s_memtime();
             // ---------------- film: Sensor::add_sample (sensor.rs:41-78) + regeneration ----------------
             if (active && end_path) {
                 if (PROBE) {
@@ -530,6 +568,14 @@ __global__ __launch_bounds__(64) void pt_kernel(DevScene sc, DevCamera cam, DevP
                 need_new = true;
                 active = s_cur < s_end;
             }
+            if (STATS) {
+                unsigned long long ts5 = __builtin_amdgcn_s_memtime();
+                tp[0] += ts1 - ts0; tp[1] += ts2 - ts1; tp[2] += ts3 - ts2; tp[3] += ts4 - ts3; tp[4] += ts5 - ts4;
+            }
+        }
+        if (STATS && lane == 0) {
+            tp[5] = __builtin_amdgcn_s_memtime() - t_loop0;
+            for (int i = 0; i < 6; ++i) atomicAdd(&stats->phase_cycles[i], tp[i]);
         }
 
         if (!PROBE && lane_valid) {
@@ -662,4 +708,13 @@ hipError_t launch_probe_occluded(const DevScene& sc, const float* o, const float
 
 namespace pt {
 uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed) { return murmur_dim_seed(dimension, seed); }
+// resident 64-thread blocks (= waves) of the render kernel on the current device: the persistent grid size
+int query_resident_waves() {
+    int dev = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 2048;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false>, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+    return prop.multiProcessorCount * per_cu;
+}
 }  // namespace pt

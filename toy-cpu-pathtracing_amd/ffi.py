@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "csrc", "libmi355pt.so")
+LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(HERE, "csrc", "libmi355pt.so")   # env override: A/B builds while tuning
 
 NONE = 0xFFFFFFFF
 SPEC_CONSTANT, SPEC_RGB_ALBEDO_SRGB, SPEC_LUT470, SPEC_TEXTURE_ALBEDO_SRGB, SPEC_SIGMOID = 0, 1, 2, 3, 4
@@ -65,10 +65,12 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest",
                                           "nodes_shadow", "tris_shadow", "closest_hits", "bounces", "spectrum_evals",
-                                          "textured_lookups")] + [("kernel_ms", C.c_double), ("launches", C.c_uint32)]
+                                          "textured_lookups")] + [("phase_cycles", C.c_uint64 * 6), ("kernel_ms", C.c_double), ("launches", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["phase_cycles"] = list(self.phase_cycles)
+        return d
 
 
 def make_camera(position, direction, up, width, height, fov_deg=45.0):
