@@ -1,0 +1,29 @@
+"""Tile-sharded frame across ranks + one film reduce.
+
+One process per GPU.  Rank r renders the 8x8 pixel tiles t with t % world == r into its own zero-initialised
+full-frame buffer of *linear* RGB sums; a single `reduce(sum)` onto rank 0 (RCCL over xGMI on GPUs, gloo in the CPU
+test) assembles the film; rank 0 resolves (mean, clip, Reinhard, sRGB OETF — non-linear, hence after the reduce).
+The renderer is passed in, so the CPU test can drive the identical logic with the oracle."""
+import torch
+import torch.distributed as dist
+
+
+def shard_of(rank, world):
+    return {"shard_index": rank, "shard_count": max(world, 1)}
+
+
+def render_frame_sharded(render_accum, accum, rank, world, reduce=True):
+    """render_accum(accum_tensor, shard_index, shard_count) adds this rank's tiles into `accum` (a torch tensor on the
+    rank's device).  Returns the reduced tensor on rank 0 (other ranks: their partial)."""
+    render_accum(accum, **shard_of(rank, world))
+    if world > 1 and reduce:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    return accum
+
+
+def max_over_ranks(seconds, world, device):
+    if world <= 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
