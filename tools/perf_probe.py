@@ -47,7 +47,7 @@ prod.render_accum_device(sc, cam, prm2, 0, 4, d_acc.value, None, stats=st)
 d = st.as_dict()
 ph = d["phase_cycles"]
 tot = max(ph[5], 1)
-names = ["regen", "closest", "shade", "shadow", "film"]
+names = ["regen", "closest", "shade", "shadow", "film", "loop", "sh_surface", "sh_bsdf", "sh_nee"]
 print(json.dumps({"tag": a.tag, "scene": a.scene, "Msamples_s": round(rate, 1), "ms": [round(x, 2) for x in ms],
-                  "phase_share": {k: round(v / tot, 3) for k, v in zip(names, ph[:5])},
+                  "phase_share": {k: round(v / tot, 3) for k, v in zip(names, ph[:9]) if k != "loop"},
                   "per_sample": {k: round(d[k] / max(d["samples"], 1), 2) for k in ("closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow", "bounces")}}))

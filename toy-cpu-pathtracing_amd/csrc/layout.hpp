@@ -151,7 +151,7 @@ struct DevParams {
 struct DevStats {
     unsigned long long samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;
     unsigned long long closest_hits, bounces, spectrum_evals, textured_lookups;
-    unsigned long long phase_cycles[6];
+    unsigned long long phase_cycles[10];
 };
 
 }  // namespace pt

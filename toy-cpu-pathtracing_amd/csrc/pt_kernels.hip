@@ -5,130 +5,164 @@
 //  * one wave owns an 8x8 pixel tile (one lane = one pixel, film sums stay in registers -> the same
 //    deterministic per-pixel summation order as the CPU loop, no atomics on the film);
 //  * waves are persistent: they pull (tile, sample-chunk) work items from a global counter;
-//  * inside a wave the path loop is a *wavefront state machine*: every iteration all 64 lanes trace one
-//    closest-hit ray together, shade together, trace one shadow ray together; a lane whose path ended
-//    regenerates the next sample of its pixel at the top of the next iteration, so lanes never idle
-//    while their neighbours finish long paths (path regeneration = in-register compaction; path state
-//    never round-trips through HBM);
+//  * path state never round-trips through HBM: every lane carries its path in registers and
+//    regenerates the next sample of its pixel when the path ends (in-register compaction);
+//  * inside a wave, lanes are a *pool of small state machines* (pt_kernel, variant 2):
+//      NEW/END -> (film, regenerate) -> TRAV(closest) -> SHADE -> TRAV(shadow) -> TRAV(closest) ...
+//    Closest-hit and any-hit rays share ONE traversal loop.  The wave alternates between traversal
+//    quanta (lanes in TRAV) and batched shading (lanes in SHADE/END/NEW) driven by __ballot/__popcll
+//    votes: a lane that finishes its ray early does not wait for the slowest ray of the wave to finish
+//    before its next ray joins the pool, which is what kept VALU lane utilisation at ~30 % and
+//    load-instruction utilisation at ~15 % in the lock-step variant (profiles/r01_v0_pmc.json);
 //  * BVH traversal keeps the per-lane stack in LDS (stack[level][lane], conflict-free) and the
 //    MurmurHash(dimension, seed) table of the Sobol sampler in LDS.
 #include <hip/hip_runtime.h>
 
-#include "layout.hpp"
-#include "pt_device.hpp"
-
 #include <algorithm>
 
+#include "layout.hpp"
+#include "pt_device.hpp"
+#include "pt_path.hpp"
+
 namespace pt {
-
-constexpr float RAY_EPS = 1e-5f;       // base_renderer.rs:34
-constexpr float SHADOW_EPS = 1e-4f;    // common.rs:12
-
-struct Frame { f3 t, b, n; };          // rows of the Render -> VertexNormalTangent matrix
-PT_DEV f3 to_local(const Frame& f, f3 v) { return mk3(dot(f.t, v), dot(f.b, v), dot(f.n, v)); }
-PT_DEV f3 to_world(const Frame& f, f3 v) { return f.t * v.x + f.b * v.y + f.n * v.z; }
-// Transform::from_shading_normal_tangent (math/src/transform.rs:186-203); the inverse of an orthonormal basis is its transpose
-PT_DEV Frame shading_frame(f3 shading_normal, f3 tangent) {
-    Frame f;
-    f.n = normalize(shading_normal);
-    f.b = normalize(cross(normalize(f.n), tangent));
-    f.t = normalize(cross(f.b, f.n));
-    return f;
-}
-// Transform::from_normal_map (transform.rs:216-244)
-PT_DEV Frame normal_map_frame(f3 nm) {
-    Frame f;
-    f.n = normalize(nm);
-    f3 cx = fabsf(f.n.x) < 0.9f ? mk3(1, 0, 0) : mk3(0, 1, 0);
-    f.t = normalize(cx - dot(f.n, cx) * f.n);
-    f.b = normalize(cross(f.n, f.t));
-    return f;
-}
-PT_DEV f3 mat3_mul(const float* m, f3 v) {   // column-major 3x3
-    return mk3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z);
-}
-PT_DEV f3 orthogonalize(f3 n, f3 v) { return normalize(v - n * dot(n, v)); }   // normal.rs:45-51
-PT_DEV f3 generate_tangent(f3 n) { return orthogonalize(n, fabsf(n.x) > 0.999f ? mk3(0, 1, 0) : mk3(1, 0, 0)); }   // normal.rs:55-65
-
-struct Surface {           // SurfaceInteraction<Render> + what the integrator needs
-    f3 p, ng, ns, tangent;
-    f2 uv;
-    uint32_t material, flags, light;
-    float light_pdf_area;
-};
-
-PT_DEV Surface load_surface(const DevScene& sc, const Hit& h) {
-    Surface s;
-    TriVerts tv = load_tri(sc.tris, h.tri);
-    s.p = tv.p0 * h.b0 + tv.p1 * h.b1 + tv.p2 * h.b2;                               // ray.rs:161-165
-    s.ng = normalize(normalize(cross(tv.p1 - tv.p0, tv.p2 - tv.p0)));                // ray.rs:167-174
-    const float4* q = (const float4*)(sc.shade + h.tri);
-    float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
-    f3 n0 = mk3(a.x, a.y, a.z), n1 = mk3(a.w, b.x, b.y), n2 = mk3(b.z, b.w, c.x);
-    f3 tan_l = mk3(c.y, c.z, c.w);
-    s.material = __float_as_uint(e.z);
-    uint32_t inst = __float_as_uint(e.w);
-    s.flags = __float_as_uint(f.x); s.light = __float_as_uint(f.y); s.light_pdf_area = f.w;
-    // geometry/impls/triangle_mesh.rs:73-97 in LOCAL space, then primitive transform (samples.rs:130-143)
-    f3 sn_l = normalize(n0 * h.b0 + n1 * h.b1 + n2 * h.b2);
-    f3 tg_l;
-    if (s.flags & 1u) {
-        s.uv = f2{d.x * h.b0 + d.z * h.b1 + e.x * h.b2, d.y * h.b0 + d.w * h.b1 + e.y * h.b2};
-        tg_l = orthogonalize(sn_l, tan_l);
-    } else {
-        s.uv = f2{0.0f, 0.0f};
-        tg_l = generate_tangent(sn_l);
-    }
-    const DevInstance* di = sc.instances + inst;
-    if (di->identity) {
-        s.ns = normalize(sn_l); s.tangent = tg_l;
-    } else {
-        s.ns = normalize(mat3_mul(di->nrm, sn_l));
-        s.tangent = mat3_mul(di->lin, tg_l);
-    }
-    return s;
-}
-
-PT_DEV DevSpectrum load_spectrum(const DevSpectrum* p) {
-    const float4* q = (const float4*)p;
-    float4 a = q[0], b = q[1];
-    DevSpectrum s;
-    s.kind = __float_as_uint(a.x); s.id = __float_as_uint(a.y); s.c[0] = a.z; s.c[1] = a.w; s.c[2] = b.x;
-    return s;
-}
-
-PT_DEV float balance_heuristic(float a, float b) { return (a == 0.0f && b == 0.0f) ? 0.0f : a / (a + b); }   // common.rs:15-20
-
-// fresnel_dielectric for one wavelength lane (material/common.rs:87-105); spectrum '/' maps x/0 -> 0
-PT_DEV float sdiv(float a, float b) { return b == 0.0f ? 0.0f : a / b; }
-PT_DEV float fresnel_dielectric1(float cos_i, float eta) {
-    cos_i = fminf(fmaxf(cos_i, 0.0f), 1.0f);
-    float sin2_i = 1.0f - cos_i * cos_i;
-    float sin2_t = sdiv(sin2_i, eta * eta);
-    float cos_t = sqrtf(fminf(fmaxf(1.0f - sin2_t, 0.0f), 1.0f));
-    float r_parl = sdiv(eta * cos_i - cos_t, eta * cos_i + cos_t);
-    float r_perp = sdiv(cos_i - eta * cos_t, cos_i + eta * cos_t);
-    return (r_parl * r_parl + r_perp * r_perp) * 0.5f;
-}
-PT_DEV bool refract(f3 wi, f3 n, float eta, f3& wt) {                         // common.rs:117-139
-    float cos_i = dot(n, wi);
-    float sin2_i = fmaxf(1.0f - cos_i * cos_i, 0.0f);
-    float sin2_t = sin2_i / (eta * eta);
-    if (sin2_t >= 1.0f) return false;
-    float cos_t = sqrtf(fmaxf(1.0f - sin2_t, 0.0f));
-    f3 w = mk3(-wi.x / eta, -wi.y / eta, -wi.z / eta) + n * (cos_i / eta - cos_t);
-    if (dot(w, w) < 1e-12f) return false;
-    wt = normalize(w);
-    return true;
-}
-
-enum : uint32_t { ST_DIFFUSE = 0, ST_SPEC_REFL = 1, ST_SPEC_TRANS = 2, ST_GLOSSY_REFL = 3, ST_GLOSSY_TRANS = 4 };
-
-struct PathOut { float* L; float* lam; float* pdf; };   // probe output (one path per lane)
 
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4   // 128 VGPRs: measured +26 % over the unconstrained 220-VGPR build (latency hiding beats the spills)
 #endif
+#ifndef PT_VARIANT
+#define PT_VARIANT 1     // 1 = lock-step wave (every lane: trace, shade, trace): 654 Msamples/s; 2 = lane pool with shared
+                         // traversal: 516 Msamples/s at best (shading batches run under-filled), kept for A/B runs
+#endif
+#ifndef PT_SHADE_TH
+#define PT_SHADE_TH 24   // batch shading once this many lanes wait (or nothing is traversing)
+#endif
+#ifndef PT_LEAF_TH
+#define PT_LEAF_TH 16    // intersect leaves once this many lanes hold one (or no lane is at an inner node)
+#endif
+#ifndef PT_QUANTUM
+#define PT_QUANTUM 24    // traversal steps between scheduling decisions
+#endif
+
+// work item -> lane assignment shared by both variants
+struct LaneJob { uint32_t px, py, s_cur, s_end; bool valid; };
+template <bool PROBE>
+PT_DEV LaneJob lane_job(uint32_t work, uint32_t lane, const DevCamera& cam, const DevParams& prm, const uint32_t* probe_xys, uint32_t n_probe) {
+    LaneJob j{0, 0, 0, 0, false};
+    if (PROBE) {
+        uint32_t qi = work * 64 + lane;
+        j.valid = qi < n_probe;
+        if (j.valid) { j.px = probe_xys[3 * qi]; j.py = probe_xys[3 * qi + 1]; j.s_cur = probe_xys[3 * qi + 2]; j.s_end = j.s_cur + 1; }
+    } else {
+        uint32_t tile_k = work / prm.chunks, chunk = work % prm.chunks;
+        uint32_t tile = prm.shard_index + tile_k * prm.shard_count;
+        uint32_t tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
+        j.px = tx * 8 + (lane & 7); j.py = ty * 8 + (lane >> 3);
+        j.valid = j.px < cam.width && j.py < cam.height;
+        j.s_cur = prm.sample_begin + chunk * prm.chunk_size;
+        j.s_end = min(j.s_cur + prm.chunk_size, prm.sample_end);
+    }
+    return j;
+}
+
+PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
+    atomicAdd(&stats->samples, (unsigned long long)st.samples);
+    atomicAdd(&stats->closest_rays, (unsigned long long)st.closest_rays);
+    atomicAdd(&stats->shadow_rays, (unsigned long long)st.shadow_rays);
+    atomicAdd(&stats->nodes_closest, (unsigned long long)st.nodes_closest);
+    atomicAdd(&stats->tris_closest, (unsigned long long)st.tris_closest);
+    atomicAdd(&stats->nodes_shadow, (unsigned long long)st.nodes_shadow);
+    atomicAdd(&stats->tris_shadow, (unsigned long long)st.tris_shadow);
+    atomicAdd(&stats->closest_hits, (unsigned long long)st.closest_hits);
+    atomicAdd(&stats->bounces, (unsigned long long)st.bounces);
+    atomicAdd(&stats->spectrum_evals, (unsigned long long)st.spectrum_evals);
+    atomicAdd(&stats->textured_lookups, (unsigned long long)st.textured_lookups);
+}
+
+#if PT_VARIANT == 1
+// ------------------------------------------------------------------------------------------------------------------
+// Variant 1: lock-step wave.  Every iteration all lanes trace one closest ray, shade, trace one shadow ray.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool STATS, bool PROBE>
+__global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
+                                                float* __restrict__ accum, unsigned* __restrict__ work_counter,
+                                                DevStats* __restrict__ stats, const uint32_t* __restrict__ probe_xys, uint32_t n_probe,
+                                                PathOut pout) {
+    __shared__ uint32_t s_stack[STACK_DEPTH * 64];
+    __shared__ uint64_t s_hash[HASH_TABLE_DIMS];
+    __shared__ unsigned s_work;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < (uint32_t)HASH_TABLE_DIMS; i += 64) s_hash[i] = dim_hash_tab[i];
+    __syncthreads();
+    uint32_t* stack = s_stack + lane;
+    SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash};
+    StatCounters st{};
+
+    for (;;) {
+        if (lane == 0) s_work = atomicAdd(work_counter, 1u);
+        __syncthreads();
+        const uint32_t work = s_work;
+        __syncthreads();
+        if (work >= prm.n_work) break;
+        LaneJob job = lane_job<PROBE>(work, lane, cam, prm, probe_xys, n_probe);
+        uint32_t s_cur = job.s_cur;
+        float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+        Path P{};
+        bool need_new = true;
+        bool active = job.valid && s_cur < job.s_end;
+        unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long t_loop0 = 0;
+        if (STATS) t_loop0 = __builtin_amdgcn_s_memtime();
+        while (__any(active)) {
+            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
+            if (STATS) ts0 = __builtin_amdgcn_s_memtime();
+            if (active && need_new) { regen_path<STATS>(P, sctx, cam, job.px, job.py, s_cur, st); need_new = false; }
+            if (STATS) ts1 = __builtin_amdgcn_s_memtime();
+            Hit hit{};
+            bool got = false;
+            if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st);
+            if (STATS) ts2 = __builtin_amdgcn_s_memtime();
+            bool end_path = false;
+            ShadowReq sh{};
+            if (active) end_path = shade_vertex<STATS>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
+            if (STATS) ts3 = __builtin_amdgcn_s_memtime();
+            if (sh.on) {
+                bool occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st);
+                if (!occluded) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
+                }
+            }
+            if (STATS) ts4 = __builtin_amdgcn_s_memtime();
+            if (active && end_path) {
+                film_add<PROBE>(P, sc, prm, acc_r, acc_g, acc_b, pout, work * 64 + lane);
+                s_cur += 1;
+                need_new = true;
+                active = s_cur < job.s_end;
+            }
+            if (STATS) {
+                unsigned long long ts5 = __builtin_amdgcn_s_memtime();
+                tp[0] += ts1 - ts0; tp[1] += ts2 - ts1; tp[2] += ts3 - ts2; tp[3] += ts4 - ts3; tp[4] += ts5 - ts4;
+                if (tsa) { tp[6] += tsa - ts2; if (tsb) { tp[7] += tsb - tsa; tp[8] += ts3 - tsb; } else tp[7] += ts3 - tsa; } else tp[6] += ts3 - ts2;
+            }
+        }
+        if (STATS && lane == 0) {
+            tp[5] = __builtin_amdgcn_s_memtime() - t_loop0;
+            for (int i = 0; i < 10; ++i) atomicAdd(&stats->phase_cycles[i], tp[i]);
+        }
+        if (!PROBE && job.valid) {
+            size_t o = ((size_t)job.py * cam.width + job.px) * 3;
+            if (prm.chunks == 1) { accum[o] += acc_r; accum[o + 1] += acc_g; accum[o + 2] += acc_b; }
+            else { atomicAdd(accum + o, acc_r); atomicAdd(accum + o + 1, acc_g); atomicAdd(accum + o + 2, acc_b); }
+        }
+    }
+    if (STATS) flush_stats(stats, st);
+}
+
+#else
+// ------------------------------------------------------------------------------------------------------------------
+// Variant 2: lane pool.  Stages per lane; closest and shadow rays share one traversal loop.
+// ------------------------------------------------------------------------------------------------------------------
+enum : uint32_t { LS_NEW = 0, LS_END = 1, LS_SHADE = 2, LS_TRAV = 3, LS_DONE = 4 };
 
 template <bool STATS, bool PROBE>
 __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
@@ -144,7 +178,6 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
     uint32_t* stack = s_stack + lane;
     SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash};
     StatCounters st{};
-    const float pdf0 = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
 
     for (;;) {
         if (lane == 0) s_work = atomicAdd(work_counter, 1u);
@@ -152,453 +185,160 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
         const uint32_t work = s_work;
         __syncthreads();
         if (work >= prm.n_work) break;
-
-        uint32_t px = 0, py = 0, s_cur = 0, s_end = 0;
-        bool lane_valid;
-        if (PROBE) {
-            uint32_t qi = work * 64 + lane;
-            lane_valid = qi < n_probe;
-            if (lane_valid) { px = probe_xys[3 * qi]; py = probe_xys[3 * qi + 1]; s_cur = probe_xys[3 * qi + 2]; s_end = s_cur + 1; }
-        } else {
-            uint32_t tile_k = work / prm.chunks, chunk = work % prm.chunks;
-            uint32_t tile = prm.shard_index + tile_k * prm.shard_count;
-            uint32_t tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
-            px = tx * 8 + (lane & 7); py = ty * 8 + (lane >> 3);
-            lane_valid = px < cam.width && py < cam.height;
-            s_cur = prm.sample_begin + chunk * prm.chunk_size;
-            s_end = min(s_cur + prm.chunk_size, prm.sample_end);
-        }
+        LaneJob job = lane_job<PROBE>(work, lane, cam, prm, probe_xys, n_probe);
+        uint32_t s_cur = job.s_cur;
         float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+        Path P{};
+        uint32_t stage = (job.valid && s_cur < job.s_end) ? LS_NEW : LS_DONE;
 
-        // ---- per-lane path state ----
-        Sampler smp{};
-        Wl wl{};
-        float T[4], L[4];
-        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
-        bool from_camera = true, prev_spec = false;
-        float pf[4] = {0, 0, 0, 0};     // f of the BSDF sample that spawned the pending ray
-        float p_pdf = 1.0f;             // its pdf
-        f3 prev_pos = mk3(0, 0, 0);
-        uint32_t depth = 0;
-        bool need_new = true;
-        bool active = lane_valid && s_cur < s_end;
+        // traversal state of this lane's current ray
+        f3 t_ro = mk3(0, 0, 0), t_rd = mk3(0, 0, 1);
+        RaySetup rs{};
+        float t_best = 0.0f;
+        int32_t cur = 0;
+        int sp = 0;
+        Hit hit{};
+        bool found = false, t_shadow = false, t_fin = false;
+        // what follows a shadow ray: the light contribution, and the next closest ray (P.ro/P.rd) unless the path ended
+        float sh_c[4] = {0, 0, 0, 0};
+        bool end_after_shadow = false;
 
-        unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long t_loop0 = 0;
         if (STATS) t_loop0 = __builtin_amdgcn_s_memtime();
-        while (__any(active)) {
-            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+
+        for (;;) {
+            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsa = 0, tsb = 0;
             if (STATS) ts0 = __builtin_amdgcn_s_memtime();
-            if (active && need_new) {
-                // base_renderer.rs:160-177: wavelengths (dim 0), pixel sample (dims 1-2), camera ray
-                sampler_start(smp, sctx, px, py, s_cur);
-                float u = get_1d(smp, sctx);
-                wl_init(wl, u);
-                f2 uv = get_2d(smp, sctx);
-                float fx = (float)px + (uv.x * 1.0f - 1.0f * 0.5f) + 0.5f;             // filter.rs:24-29, camera.rs:68-72
-                float fy = (float)py + (uv.y * 1.0f - 1.0f * 0.5f) + 0.5f;
-                float dx = (2.0f * fx / (float)cam.width - 1.0f) * cam.aspect * cam.tan_half_fov;   // camera.rs:51-65
-                float dy = (1.0f - 2.0f * fy / (float)cam.height) * cam.tan_half_fov;
-                f3 dc = normalize(mk3(dx, dy, -1.0f));
-                f3 s = mk3(cam.s[0], cam.s[1], cam.s[2]), uu = mk3(cam.u[0], cam.u[1], cam.u[2]), ff = mk3(cam.f[0], cam.f[1], cam.f[2]);
-                rd = normalize(s * dc.x + uu * dc.y + (-ff) * dc.z);
-                ro = mk3(0, 0, 0) + rd * RAY_EPS;                                       // move_forward
+            // ---- (1) rays that finished: shadow -> apply + continue with the pending ray; closest -> SHADE ----
+            if (stage == LS_TRAV && t_fin) {
+                if (t_shadow) {
+                    if (!found) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { T[i] = 1.0f; L[i] = 0.0f; }
-                from_camera = true; depth = 0; need_new = false;
-                if (STATS) st.samples++;
+                        for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh_c[i];
+                    }
+                    if (end_after_shadow) stage = LS_END;
+                    else {
+                        t_ro = P.ro; t_rd = P.rd; rs = setup_ray(t_rd); t_best = 3.402823466e+38f;
+                        cur = sc.root; sp = 0; found = false; t_shadow = false; t_fin = false;
+                        if (STATS) st.closest_rays++;
+                    }
+                } else {
+                    stage = LS_SHADE;
+                    if (STATS && found) st.closest_hits++;
+                }
             }
-
+            // ---- (2) batched film / regenerate / shade ----
+            const unsigned long long m_wait = __ballot(stage == LS_NEW || stage == LS_END || stage == LS_SHADE);
+            const unsigned long long m_trav = __ballot(stage == LS_TRAV);
+            if (m_wait == 0ull && m_trav == 0ull) break;                       // every lane is DONE
+            if (m_wait != 0ull && (__popcll(m_wait) >= PT_SHADE_TH || m_trav == 0ull)) {
+                if (stage == LS_END) {
+                    film_add<PROBE>(P, sc, prm, acc_r, acc_g, acc_b, pout, work * 64 + lane);
+                    s_cur += 1;
+                    stage = s_cur < job.s_end ? LS_NEW : LS_DONE;
+                }
+                if (STATS) ts1 = __builtin_amdgcn_s_memtime();
+                bool start_closest = false;
+                if (stage == LS_NEW) { regen_path<STATS>(P, sctx, cam, job.px, job.py, s_cur, st); start_closest = true; }
+                else if (stage == LS_SHADE) {
+                    ShadowReq sh{};
+                    bool end_path = shade_vertex<STATS>(P, sc, prm, sctx, found, hit, sh, st, tsa, tsb);
+                    if (sh.on) {
+                        t_ro = sh.o; t_rd = sh.d; rs = setup_ray(t_rd); t_best = sh.t;
+                        cur = sc.root; sp = 0; found = false; t_shadow = true; t_fin = false;
+                        end_after_shadow = end_path;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sh_c[i] = sh.c[i];
+                        stage = LS_TRAV;
+                        if (STATS) st.shadow_rays++;
+                    } else if (end_path) stage = LS_END;
+                    else start_closest = true;
+                }
+                if (start_closest) {
+                    t_ro = P.ro; t_rd = P.rd; rs = setup_ray(t_rd); t_best = 3.402823466e+38f;
+                    cur = sc.root; sp = 0; found = false; t_shadow = false; t_fin = false;
+                    stage = LS_TRAV;
+                    if (STATS) st.closest_rays++;
+                }
+                if (STATS) {
+                    ts2 = __builtin_amdgcn_s_memtime();
+                    tp[4] += ts1 - ts0; tp[2] += ts2 - ts1;
+                }
+                continue;   // re-vote: lanes that just ended may be filmed/regenerated before the next quantum
+            }
+            // ---- (3) traversal quantum over the pool ----
             if (STATS) ts1 = __builtin_amdgcn_s_memtime();
-            // ---------------- extend: closest hit for every active lane ----------------
-            Hit hit{};
-            bool got = false;
-            if (active) got = trace_closest<STATS>(sc, ro, rd, 3.402823466e+38f, stack, hit, st);
-
-            if (STATS) ts2 = __builtin_amdgcn_s_memtime();
-            bool end_path = false;
-            bool do_shadow = false;
-            f3 sh_o = mk3(0, 0, 0), sh_d = mk3(0, 0, 1);
-            float sh_t = 0.0f;
-            float sh_c[4] = {0, 0, 0, 0};
-
-            if (active) {
-                if (!got) {
-                    end_path = true;   // no infinite lights in scope: radiance 0 (base_renderer.rs:180-186,240-253)
-                } else {
-                    Surface sf = load_surface(sc, hit);
-                    const DevMaterial* mat = sc.materials + sf.material;
-                    const uint32_t mtype = mat->type;
-                    const bool emissive = mtype == MT_EMISSIVE;
-                    float Le[4] = {0, 0, 0, 0};
-                    if (emissive) {                                                      // evaluate_emissive_surface :54-73
-                        DevSpectrum rs = load_spectrum(&mat->color);
-                        eval_spectrum<STATS>(sc, rs, wl, sf.uv, Le, st);
-                        float inten = mat->intensity;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) Le[i] = Le[i] * inten;
-                    }
-                    if (from_camera) {
-                        if (emissive) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) L[i] = L[i] + T[i] * Le[i];      // :190-194
-                        }
-                    } else {
-                        // calculate_bsdf_contribution (pt :33-47, nee :120-137, mis :151-181)
-                        float tf = 1.0f / p_pdf;
-                        if (emissive) {
-                            float w = 1.0f;
-                            if (prm.strategy == 1u) w = prev_spec ? 1.0f : 0.0f;
-                            else if (prm.strategy == 2u && !prev_spec) {
-                                // Scene::pdf_light_sample (scene.rs:156-182); light probability = phi-weighted pick
-                                float wsum = 0.0f, wme = 0.0f;
-                                if (sc.n_lights == 1u) {
-                                    // one light (every BASELINE config): phi(lambda) is Le * area, already evaluated
-                                    // (emissive radiance cannot be a texture, so Le does not depend on uv)
-                                    float sum = 0.0f;
-                                    float area = sc.lights[0].area_sum;
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) sum += Le[i] * area;
-                                    wsum = wme = sum / 4.0f;
-                                } else
-                                for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                                    DevLight lt = sc.lights[li];
-                                    const DevMaterial* lm = sc.materials + lt.material;
-                                    float ph[4];
-                                    DevSpectrum ls = load_spectrum(&lm->color);
-                                    eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                                    float inten = lm->intensity;
-                                    float sum = 0.0f;
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) sum += (ph[i] * inten) * lt.area_sum;
-                                    float wt = sum / 4.0f;
-                                    wsum += wt;
-                                    if (li == sf.light) wme = wt;
-                                }
-                                float probability = wsum == 0.0f ? 0.0f : wme / wsum;
-                                f3 dv = prev_pos - sf.p;
-                                float distance = length(dv);
-                                f3 wo_l = -normalize(dv);
-                                float pdf_dir = sf.light_pdf_area * (distance * distance) / fabsf(dot(sf.ng, wo_l));
-                                w = balance_heuristic(p_pdf, probability * pdf_dir);
-                            }
-                            if (w != 0.0f || prm.strategy != 1u) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * ((pf[i] * Le[i]) * tf)) * w;
+            for (int q = 0; q < PT_QUANTUM; ++q) {
+                const bool trav = stage == LS_TRAV && !t_fin;
+                const bool at_node = trav && cur >= 0;
+                if (at_node) {
+                    const float4* qn = (const float4*)(sc.nodes + cur);
+                    float4 nx = qn[0], ny = qn[1], nz = qn[2];
+                    int2 ch = *(const int2*)(qn + 3);
+                    if (STATS) { if (t_shadow) st.nodes_shadow++; else st.nodes_closest++; }
+                    float l0x = (nx.x - t_ro.x) * rs.inv.x, h0x = (nx.z - t_ro.x) * rs.inv.x;
+                    float l1x = (nx.y - t_ro.x) * rs.inv.x, h1x = (nx.w - t_ro.x) * rs.inv.x;
+                    float l0y = (ny.x - t_ro.y) * rs.inv.y, h0y = (ny.z - t_ro.y) * rs.inv.y;
+                    float l1y = (ny.y - t_ro.y) * rs.inv.y, h1y = (ny.w - t_ro.y) * rs.inv.y;
+                    float l0z = (nz.x - t_ro.z) * rs.inv.z, h0z = (nz.z - t_ro.z) * rs.inv.z;
+                    float l1z = (nz.y - t_ro.z) * rs.inv.z, h1z = (nz.w - t_ro.z) * rs.inv.z;
+                    float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+                    float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_best));
+                    float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+                    float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_best));
+                    bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+                    if (hit0 && hit1) {
+                        bool first0 = n0 <= n1;
+                        stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp;
+                        cur = first0 ? ch.x : ch.y;
+                    } else if (hit0) cur = ch.x;
+                    else if (hit1) cur = ch.y;
+                    else if (sp == 0) t_fin = true;
+                    else { --sp; cur = (int32_t)stack[sp * 64]; }
+                }
+                // leaves are postponed until enough lanes hold one, so the triangle test runs on a well-filled wave
+                const bool at_leaf = stage == LS_TRAV && !t_fin && cur < 0;
+                const unsigned long long m_leaf = __ballot(at_leaf);
+                const unsigned long long m_node = __ballot(stage == LS_TRAV && !t_fin && cur >= 0);
+                if (m_leaf != 0ull && (__popcll(m_leaf) >= PT_LEAF_TH || m_node == 0ull)) {
+                    if (at_leaf) {
+                        uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+                        for (uint32_t i = 0; i < cnt; ++i) {
+                            TriVerts tv = load_tri(sc.tris, first + i);
+                            float t, b0, b1, b2;
+                            if (STATS) { if (t_shadow) st.tris_shadow++; else st.tris_closest++; }
+                            if (intersect_triangle(t_ro, t_rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
+                                if (t_shadow) { found = true; break; }
+                                if (!found || t < t_best) { found = true; t_best = t; hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = first + i; }
                             }
                         }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) T[i] = T[i] * (pf[i] * tf);
-                        // apply_russian_roulette (:76-92)
-                        float p = fmaxf(fmaxf(fmaxf(fmaxf(-INFINITY, T[0]), T[1]), T[2]), T[3]);
-                        if (!(p >= 1.0f)) {
-                            float ur = get_1d(smp, sctx);
-                            if (ur < p) {
-                                if (p != 0.0f) {
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) T[i] = T[i] / p;
-                                }
-                            } else end_path = true;
-                        }
-                    }
-                    if (!end_path) {
-                        depth += 1;                                                       // for _ in 1..=max_depth (:197)
-                        if (depth > prm.max_depth || emissive) end_path = true;           // as_bsdf_material() == None (:199-202)
-                    }
-                    if (!end_path) {
-                        if (STATS) st.bounces++;
-                        Frame fr = shading_frame(sf.ns, sf.tangent);
-                        f3 wo_r = -rd;                                                    // Intersection.wo
-                        f3 wo = to_local(fr, wo_r);
-                        f3 ng_t = normalize(to_local(fr, sf.ng));                         // Transform * Normal renormalises
-                        float uc = get_1d(smp, sctx);
-                        f2 uv = get_2d(smp, sctx);
-                        // normal map frame (identity without a normal texture)
-                        Frame nf;
-                        if (mat->normal_tex != 0xffffffffu) {
-                            float rgb[3];
-                            bilinear_rgb(sc, mat->normal_tex, sf.uv, rgb);                // normal_texture.rs:39-66
-                            float nx = rgb[0] * 2.0f - 1.0f, ny = rgb[1] * 2.0f - 1.0f, nz = rgb[2] * 2.0f - 1.0f;
-                            if (mat->normal_flip_y) ny = -ny;
-                            float len = sqrtf(nx * nx + ny * ny + nz * nz);
-                            f3 nm = mk3(0, 0, 1);
-                            if (len > 0.0f) nm = normalize(normalize(mk3(nx / len, ny / len, nz / len)));
-                            nf = normal_map_frame(nm);
-                        } else {
-                            nf.t = mk3(1, 0, 0); nf.b = mk3(0, 1, 0); nf.n = mk3(0, 0, 1);
-                        }
-                        f3 wo_nm = to_local(nf, wo);
-                        bool sampled = false, specular = false;
-                        f3 wi_sh = mk3(0, 0, 1);
-                        float s_f[4] = {0, 0, 0, 0}, s_pdf = 0.0f;
-                        float geo_wo = dot(ng_t, wo);
-
-                        if (mtype == MT_LAMBERT) {
-                            // LambertMaterial::sample (lambert_material.rs:42-97) + NormalizedLambertBsdf (lambert.rs:38-75)
-                            float albedo[4];
-                            DevSpectrum cs = load_spectrum(&mat->color);
-                            eval_spectrum<STATS>(sc, cs, wl, sf.uv, albedo, st);
-                            if (wo_nm.z != 0.0f) {
-                                float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                                f3 wi = mk3(r * cosf(th), r * sinf(th), sqrtf(1.0f - uv.x));
-                                if (wo_nm.z < 0.0f) wi.z = -wi.z;
-                                if (wi.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi.z)) {
-                                    f3 w = to_world(nf, wi);
-                                    float gwi = dot(ng_t, w);
-                                    if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) {
-                                        sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) / PI_F;
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) s_f[i] = albedo[i] * fabsf(wi.z) / PI_F;
-                                    }
-                                }
-                            }
-                            // NEE runs for every non-specular sample *including failed ones* (samples.rs:63-71, base_renderer.rs:218)
-                            if (prm.strategy != 0u) {
-                                // light pick: LightSampler (light_sampler.rs:26-43,190-220)
-                                float ul = get_1d(smp, sctx);
-                                // phi-weighted light pick.  The picked light's radiance is evaluated ONCE and doubles as its
-                                // phi weight (emissive radiance is never a texture, so it does not depend on uv).
-                                uint32_t pick = 0; float wsum = 0.0f, wpick = 0.0f;
-                                float lrad[4];
-                                if (sc.n_lights == 1u) {
-                                    const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
-                                    DevSpectrum ls0 = load_spectrum(&lm0->color);
-                                    eval_spectrum<STATS>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
-                                    float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
-                                    wsum = wpick = sum / 4.0f;
-                                } else {
-                                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                                        DevLight lt = sc.lights[li];
-                                        const DevMaterial* lm = sc.materials + lt.material;
-                                        float ph[4];
-                                        DevSpectrum ls = load_spectrum(&lm->color);
-                                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                                        float sum = 0.0f;
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
-                                        wsum += sum / 4.0f;
-                                    }
-                                    float cum = 0.0f; bool chosen = false;
-                                    pick = sc.n_lights - 1;
-                                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                                        DevLight lt = sc.lights[li];
-                                        const DevMaterial* lm = sc.materials + lt.material;
-                                        float ph[4];
-                                        DevSpectrum ls = load_spectrum(&lm->color);
-                                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                                        float sum = 0.0f;
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
-                                        float wt = sum / 4.0f;
-                                        cum += wt;
-                                        if (!chosen && (ul < cum / wsum || li == sc.n_lights - 1)) {
-                                            chosen = true; pick = li; wpick = wt;
-#pragma unroll
-                                            for (int i = 0; i < 4; ++i) lrad[i] = ph[i];
-                                        }
-                                    }
-                                }
-                                if (sc.n_lights > 0 && wsum != 0.0f) {
-                                    float lprob = wpick / wsum;
-                                    float s1 = get_1d(smp, sctx);
-                                    f2 luv = get_2d(smp, sctx);
-                                    // EmissiveTriangleMesh::sample_radiance (emissive_triangle_mesh.rs:176-308)
-                                    DevLight lt = sc.lights[pick];
-                                    // first k with s < cdf[k] (else 0, :185-191).  The cdf is non-decreasing, so that index is the
-                                    // number of entries <= s: independent loads instead of a chain of dependent ones.
-                                    uint32_t cnt = 0;
-                                    for (uint32_t k = 0; k < lt.n_tris; ++k) cnt += (s1 < sc.light_tris[lt.first_tri + k].cdf) ? 0u : 1u;
-                                    uint32_t tsel = cnt < lt.n_tris ? cnt : 0u;
-                                    const float4* q = (const float4*)(sc.light_tris + lt.first_tri + tsel);
-                                    float4 qa = q[0], qb = q[1], qc = q[2];
-                                    f3 p0 = mk3(qa.x, qa.y, qa.z), p1 = mk3(qa.w, qb.x, qb.y), p2 = mk3(qb.z, qb.w, qc.x);
-                                    float b0, b1;
-                                    if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
-                                    float b2 = 1.0f - b0 - b1;
-                                    f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
-                                    f3 ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
-                                    const DevMaterial* lm = sc.materials + lt.material;
-                                    float pdf_a = 1.0f / lt.area_sum;
-                                    f3 dv = lp - sf.p;
-                                    f3 wi_r = normalize(dv);
-                                    float distance = length(lp - sf.p);
-                                    float pdf_dir = pdf_a * (distance * distance) / fmaxf(fabsf(dot(ln, -wi_r)), 1e-8f);
-                                    // evaluate_area_light{,_with_mis} (common.rs:82-171)
-                                    f3 wi_t = to_local(fr, wi_r);
-                                    f3 wi_nm = to_local(nf, wi_t);
-                                    float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
-                                    float gwi = dot(ng_t, wi_t);
-                                    if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
-                                        pdf_b = fabsf(wi_nm.z) / PI_F;
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) fl[i] = albedo[i] * fabsf(wi_nm.z) / PI_F;
-                                    }
-                                    float dist2 = dot(dv, dv);
-                                    f3 ln_t = normalize(to_local(fr, ln));
-                                    float g = fabsf(dot(ln_t, -wi_t)) / dist2;
-                                    float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
-                                    do_shadow = true;
-                                    sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        sh_c[i] = (T[i] * ((fl[i] * (lrad[i] * lm->intensity)) * g / (pdf_a * lprob))) * wgt;
-                                }
-                            }
-                        } else if (mtype == MT_GLASS || mtype == MT_PLASTIC) {
-                            // GlassMaterial/PlasticMaterial::sample -> DielectricBsdf::sample_specular (dielectric.rs:380-466)
-                            float eta[4];
-                            DevSpectrum es = load_spectrum(&mat->eta);
-                            eval_spectrum<STATS>(sc, es, wl, sf.uv, eta, st);
-                            bool eta_const = (eta[1] == eta[0]) && (eta[2] == eta[0]) && (eta[3] == eta[0]);
-                            if (eta[0] == 0.0f) { eta[0] = eta[1] = eta[2] = eta[3] = 1.0f; eta_const = true; }   // DielectricBsdf::new :144-148
-                            bool entering = geo_wo > 0.0f;
-                            bool thin = mat->thin != 0;
-                            if (wo_nm.z != 0.0f) {
-                                float er[4], fr4[4], favg;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) er[i] = (thin || entering) ? eta[i] : sdiv(1.0f, eta[i]);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) fr4[i] = fresnel_dielectric1(fabsf(wo_nm.z), er[i]);
-                                favg = (((0.0f + fr4[0]) + fr4[1]) + fr4[2] + fr4[3]) / 4.0f;
-                                float pr, pt;
-                                if (thin) {                                                   // calculate_thin_surface_coefficients :367-378
-                                    float r = favg, t = 1.0f - r, r2 = r * r;
-                                    pr = r2 > 1.0f ? 1.0f : r + (t * t * r) / (1.0f - r2);
-                                    pt = t;
-                                } else { pr = favg; pt = 1.0f - pr; }
-                                f3 wi = mk3(0, 0, 1);
-                                if (uc < pr / (pr + pt)) {
-                                    if (!(fabsf(wo_nm.z) < 1e-6f)) {
-                                        sampled = true; specular = true; wi = mk3(-wo_nm.x, -wo_nm.y, wo_nm.z); s_pdf = pr / (pr + pt);
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) s_f[i] = fr4[i];
-                                    }
-                                } else if (thin) {
-                                    wi = mk3(-wo_nm.x, -wo_nm.y, -wo_nm.z);
-                                    if (wi.z != 0.0f) {
-                                        sampled = true; specular = true; s_pdf = pt / (pr + pt);
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) s_f[i] = 1.0f - fr4[i];
-                                    }
-                                } else {
-                                    if (!eta_const) wl.term = true;                           // terminate_secondary :446-448
-                                    f3 n = entering ? mk3(0, 0, 1) : mk3(0, 0, -1);
-                                    f3 wt;
-                                    if (refract(wo_nm, n, er[0], wt) && wt.z != 0.0f) {
-                                        sampled = true; specular = true; wi = wt; s_pdf = pt / (pr + pt);
-                                        float e2 = er[0] * er[0];
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) s_f[i] = sdiv(1.0f - fr4[i], e2);
-                                    }
-                                }
-                                if (sampled) {
-                                    if (mtype == MT_PLASTIC && dot(wi, wo_nm) < 0.0f) {          // plastic_material.rs:123-126 (random uv, Q15)
-                                        float col[4];
-                                        DevSpectrum cs = load_spectrum(&mat->color);
-                                        eval_spectrum<STATS>(sc, cs, wl, uv, col, st);
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) s_f[i] = s_f[i] * col[i];
-                                    }
-                                    wi_sh = to_world(nf, wi);
-                                }
-                            }
-                            // failed dielectric samples are "Diffuse" (non-specular): the reference then runs NEE with
-                            // f == 0 and ends the path; nothing observable happens, so it is skipped here.
-                        }
-
-                        if (!sampled) {
-                            end_path = true;                                              // process_bsdf_sampling -> None (:102-104,240-253)
-                        } else {
-                            // spawn the next ray (:106-121)
-                            f3 wi_r = to_world(fr, wi_sh);
-                            float sg = dot(sf.ng, wi_r) < 0.0f ? -1.0f : 1.0f;
-                            f3 org = sf.p + (sg * sf.ng) * RAY_EPS;
-                            rd = wi_r; ro = org + rd * RAY_EPS;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) pf[i] = s_f[i];
-                            p_pdf = s_pdf; prev_spec = specular; prev_pos = sf.p; from_camera = false;
-                        }
+                        if (t_shadow && found) t_fin = true;                 // any hit ends a shadow ray
+                        else if (sp == 0) t_fin = true;
+                        else { --sp; cur = (int32_t)stack[sp * 64]; }
                     }
                 }
+                // leave the quantum when the pool has drained enough to make a scheduling decision worthwhile
+                const unsigned long long m_live = __ballot(stage == LS_TRAV && !t_fin);
+                if (m_live == 0ull) break;
+                if (__popcll(__ballot(stage == LS_TRAV && t_fin)) + __popcll(m_wait) >= PT_SHADE_TH) break;
             }
-
-            if (STATS) ts3 = __builtin_amdgcn_s_memtime();
-            // ---------------- connect: shadow rays of every lane that sampled a light ----------------
-            if (do_shadow) {
-                bool occluded = trace_any<STATS>(sc, sh_o, sh_d, sh_t, stack, st);
-                if (!occluded) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) L[i] = L[i] + sh_c[i];
-                }
-            }
-
-            if (STATS) ts4 = __builtin_amdgcn_s_memtime();
-            // ---------------- film: Sensor::add_sample (sensor.rs:41-78) + regeneration ----------------
-            if (active && end_path) {
-                if (PROBE) {
-                    uint32_t qi = work * 64 + lane;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        pout.L[4 * qi + i] = L[i]; pout.lam[4 * qi + i] = wl.lam[i];
-                        pout.pdf[4 * qi + i] = wl.term ? (i == 0 ? pdf0 / 4.0f : 0.0f) : pdf0;
-                    }
-                } else {
-                    float X = 0.0f, Y = 0.0f, Z = 0.0f;
-                    const float4* cmf = (const float4*)sc.cmf;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (k == 0 || !wl.term) {
-                            int idx = (int)floorf(wl.lam[k] - LAMBDA_MIN);
-                            if (idx == 470) idx = 0;
-                            float pdf = wl.term ? pdf0 / 4.0f : pdf0;
-                            float c = L[k] / pdf / 4.0f;
-                            float4 m = cmf[idx];
-                            X += c * m.x; Y += c * m.y; Z += c * m.z;
-                        }
-                    }
-                    const float* M = prm.xyz_to_rgb;   // row-major; glam Mat3*Vec3 = col0*x + col1*y + col2*z
-                    float r = M[0] * X + M[1] * Y + M[2] * Z;
-                    float g = M[3] * X + M[4] * Y + M[5] * Z;
-                    float b = M[6] * X + M[7] * Y + M[8] * Z;
-                    acc_r += r * prm.exposure; acc_g += g * prm.exposure; acc_b += b * prm.exposure;
-                }
-                s_cur += 1;
-                need_new = true;
-                active = s_cur < s_end;
-            }
-            if (STATS) {
-                unsigned long long ts5 = __builtin_amdgcn_s_memtime();
-                tp[0] += ts1 - ts0; tp[1] += ts2 - ts1; tp[2] += ts3 - ts2; tp[3] += ts4 - ts3; tp[4] += ts5 - ts4;
-            }
+            if (STATS) { ts2 = __builtin_amdgcn_s_memtime(); tp[1] += ts2 - ts1; tp[0] += ts1 - ts0; }
         }
+
         if (STATS && lane == 0) {
             tp[5] = __builtin_amdgcn_s_memtime() - t_loop0;
-            for (int i = 0; i < 6; ++i) atomicAdd(&stats->phase_cycles[i], tp[i]);
+            for (int i = 0; i < 10; ++i) atomicAdd(&stats->phase_cycles[i], tp[i]);
         }
-
-        if (!PROBE && lane_valid) {
-            size_t o = ((size_t)py * cam.width + px) * 3;
+        if (!PROBE && job.valid) {
+            size_t o = ((size_t)job.py * cam.width + job.px) * 3;
             if (prm.chunks == 1) { accum[o] += acc_r; accum[o + 1] += acc_g; accum[o + 2] += acc_b; }
             else { atomicAdd(accum + o, acc_r); atomicAdd(accum + o + 1, acc_g); atomicAdd(accum + o + 2, acc_b); }
         }
     }
-
-    if (STATS) {
-        atomicAdd(&stats->samples, (unsigned long long)st.samples);
-        atomicAdd(&stats->closest_rays, (unsigned long long)st.closest_rays);
-        atomicAdd(&stats->shadow_rays, (unsigned long long)st.shadow_rays);
-        atomicAdd(&stats->nodes_closest, (unsigned long long)st.nodes_closest);
-        atomicAdd(&stats->tris_closest, (unsigned long long)st.tris_closest);
-        atomicAdd(&stats->nodes_shadow, (unsigned long long)st.nodes_shadow);
-        atomicAdd(&stats->tris_shadow, (unsigned long long)st.tris_shadow);
-        atomicAdd(&stats->closest_hits, (unsigned long long)st.closest_hits);
-        atomicAdd(&stats->bounces, (unsigned long long)st.bounces);
-        atomicAdd(&stats->spectrum_evals, (unsigned long long)st.spectrum_evals);
-        atomicAdd(&stats->textured_lookups, (unsigned long long)st.textured_lookups);
-    }
+    if (STATS) flush_stats(stats, st);
 }
+#endif
 
 // Sensor::to_rgb (sensor.rs:81-88) + ReinhardToneMap (tone_map.rs:20-28) + sRGB OETF (eotf.rs:54-61)
 __global__ void resolve_kernel(const float* __restrict__ accum, uint32_t n_values, float inv_unused, uint32_t spp, float* __restrict__ out) {

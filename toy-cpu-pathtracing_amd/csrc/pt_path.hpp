@@ -1,0 +1,518 @@
+// Path state and the per-vertex stages of BaseSrgbRenderer::render (renderer/src/renderer/base_renderer.rs:146-280) as
+// device functions shared by the kernel variants in pt_kernels.hip.  All state lives in registers.
+#pragma once
+#include "pt_device.hpp"
+
+namespace pt {
+
+constexpr float RAY_EPS = 1e-5f;       // base_renderer.rs:34
+constexpr float SHADOW_EPS = 1e-4f;    // common.rs:12
+
+struct Frame { f3 t, b, n; };          // rows of the Render -> VertexNormalTangent matrix
+PT_DEV f3 to_local(const Frame& f, f3 v) { return mk3(dot(f.t, v), dot(f.b, v), dot(f.n, v)); }
+PT_DEV f3 to_world(const Frame& f, f3 v) { return f.t * v.x + f.b * v.y + f.n * v.z; }
+// Transform::from_shading_normal_tangent (math/src/transform.rs:186-203); the inverse of an orthonormal basis is its transpose
+PT_DEV Frame shading_frame(f3 shading_normal, f3 tangent) {
+    Frame f;
+    f.n = normalize(shading_normal);
+    f.b = normalize(cross(normalize(f.n), tangent));
+    f.t = normalize(cross(f.b, f.n));
+    return f;
+}
+// Transform::from_normal_map (transform.rs:216-244)
+PT_DEV Frame normal_map_frame(f3 nm) {
+    Frame f;
+    f.n = normalize(nm);
+    f3 cx = fabsf(f.n.x) < 0.9f ? mk3(1, 0, 0) : mk3(0, 1, 0);
+    f.t = normalize(cx - dot(f.n, cx) * f.n);
+    f.b = normalize(cross(f.n, f.t));
+    return f;
+}
+PT_DEV f3 mat3_mul(const float* m, f3 v) {   // column-major 3x3
+    return mk3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z);
+}
+PT_DEV f3 orthogonalize(f3 n, f3 v) { return normalize(v - n * dot(n, v)); }   // normal.rs:45-51
+PT_DEV f3 generate_tangent(f3 n) { return orthogonalize(n, fabsf(n.x) > 0.999f ? mk3(0, 1, 0) : mk3(1, 0, 0)); }   // normal.rs:55-65
+
+struct Surface {           // SurfaceInteraction<Render> + what the integrator needs
+    f3 p, ng, ns, tangent;
+    f2 uv;
+    uint32_t material, flags, light;
+    float light_pdf_area;
+};
+
+PT_DEV Surface load_surface(const DevScene& sc, const Hit& h) {
+    Surface s;
+    TriVerts tv = load_tri(sc.tris, h.tri);
+    s.p = tv.p0 * h.b0 + tv.p1 * h.b1 + tv.p2 * h.b2;                               // ray.rs:161-165
+    s.ng = normalize(normalize(cross(tv.p1 - tv.p0, tv.p2 - tv.p0)));                // ray.rs:167-174
+    const float4* q = (const float4*)(sc.shade + h.tri);
+    float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
+    f3 n0 = mk3(a.x, a.y, a.z), n1 = mk3(a.w, b.x, b.y), n2 = mk3(b.z, b.w, c.x);
+    f3 tan_l = mk3(c.y, c.z, c.w);
+    s.material = __float_as_uint(e.z);
+    uint32_t inst = __float_as_uint(e.w);
+    s.flags = __float_as_uint(f.x); s.light = __float_as_uint(f.y); s.light_pdf_area = f.w;
+    // geometry/impls/triangle_mesh.rs:73-97 in LOCAL space, then primitive transform (samples.rs:130-143)
+    f3 sn_l = normalize(n0 * h.b0 + n1 * h.b1 + n2 * h.b2);
+    f3 tg_l;
+    if (s.flags & 1u) {
+        s.uv = f2{d.x * h.b0 + d.z * h.b1 + e.x * h.b2, d.y * h.b0 + d.w * h.b1 + e.y * h.b2};
+        tg_l = orthogonalize(sn_l, tan_l);
+    } else {
+        s.uv = f2{0.0f, 0.0f};
+        tg_l = generate_tangent(sn_l);
+    }
+    const DevInstance* di = sc.instances + inst;
+    if (di->identity) {
+        s.ns = normalize(sn_l); s.tangent = tg_l;
+    } else {
+        s.ns = normalize(mat3_mul(di->nrm, sn_l));
+        s.tangent = mat3_mul(di->lin, tg_l);
+    }
+    return s;
+}
+
+PT_DEV DevSpectrum load_spectrum(const DevSpectrum* p) {
+    const float4* q = (const float4*)p;
+    float4 a = q[0], b = q[1];
+    DevSpectrum s;
+    s.kind = __float_as_uint(a.x); s.id = __float_as_uint(a.y); s.c[0] = a.z; s.c[1] = a.w; s.c[2] = b.x;
+    return s;
+}
+
+PT_DEV float balance_heuristic(float a, float b) { return (a == 0.0f && b == 0.0f) ? 0.0f : a / (a + b); }   // common.rs:15-20
+
+// fresnel_dielectric for one wavelength lane (material/common.rs:87-105); spectrum '/' maps x/0 -> 0
+PT_DEV float sdiv(float a, float b) { return b == 0.0f ? 0.0f : a / b; }
+PT_DEV float fresnel_dielectric1(float cos_i, float eta) {
+    cos_i = fminf(fmaxf(cos_i, 0.0f), 1.0f);
+    float sin2_i = 1.0f - cos_i * cos_i;
+    float sin2_t = sdiv(sin2_i, eta * eta);
+    float cos_t = sqrtf(fminf(fmaxf(1.0f - sin2_t, 0.0f), 1.0f));
+    float r_parl = sdiv(eta * cos_i - cos_t, eta * cos_i + cos_t);
+    float r_perp = sdiv(cos_i - eta * cos_t, cos_i + eta * cos_t);
+    return (r_parl * r_parl + r_perp * r_perp) * 0.5f;
+}
+PT_DEV bool refract(f3 wi, f3 n, float eta, f3& wt) {                         // common.rs:117-139
+    float cos_i = dot(n, wi);
+    float sin2_i = fmaxf(1.0f - cos_i * cos_i, 0.0f);
+    float sin2_t = sin2_i / (eta * eta);
+    if (sin2_t >= 1.0f) return false;
+    float cos_t = sqrtf(fmaxf(1.0f - sin2_t, 0.0f));
+    f3 w = mk3(-wi.x / eta, -wi.y / eta, -wi.z / eta) + n * (cos_i / eta - cos_t);
+    if (dot(w, w) < 1e-12f) return false;
+    wt = normalize(w);
+    return true;
+}
+
+enum : uint32_t { ST_DIFFUSE = 0, ST_SPEC_REFL = 1, ST_SPEC_TRANS = 2, ST_GLOSSY_REFL = 3, ST_GLOSSY_TRANS = 4 };
+
+
+
+struct Path {
+    Sampler smp;
+    Wl wl;
+    float T[4], L[4];
+    f3 ro, rd;                 // next closest-hit ray
+    float pf[4];               // f of the BSDF sample that spawned that ray
+    float p_pdf;               // its pdf
+    f3 prev_pos;               // the vertex it leaves (MIS weight of an emissive hit needs it)
+    uint32_t depth;
+    bool from_camera, prev_spec;
+};
+struct ShadowReq { bool on; f3 o, d; float t; float c[4]; };   // pending light connection: ray + contribution if unoccluded
+
+// base_renderer.rs:160-177: start sample `s_cur` of pixel (px, py)
+template <bool STATS>
+PT_DEV void regen_path(Path& P, const SamplerCtx& sctx, const DevCamera& cam, uint32_t px, uint32_t py, uint32_t s_cur, StatCounters& st) {
+    Sampler& smp = P.smp; Wl& wl = P.wl; float* T = P.T; float* L = P.L; f3& ro = P.ro; f3& rd = P.rd;
+    bool& from_camera = P.from_camera; uint32_t& depth = P.depth; bool need_new = true;
+
+    // base_renderer.rs:160-177: wavelengths (dim 0), pixel sample (dims 1-2), camera ray
+    sampler_start(smp, sctx, px, py, s_cur);
+    float u = get_1d(smp, sctx);
+    wl_init(wl, u);
+    f2 uv = get_2d(smp, sctx);
+    float fx = (float)px + (uv.x * 1.0f - 1.0f * 0.5f) + 0.5f;             // filter.rs:24-29, camera.rs:68-72
+    float fy = (float)py + (uv.y * 1.0f - 1.0f * 0.5f) + 0.5f;
+    float dx = (2.0f * fx / (float)cam.width - 1.0f) * cam.aspect * cam.tan_half_fov;   // camera.rs:51-65
+    float dy = (1.0f - 2.0f * fy / (float)cam.height) * cam.tan_half_fov;
+    f3 dc = normalize(mk3(dx, dy, -1.0f));
+    f3 s = mk3(cam.s[0], cam.s[1], cam.s[2]), uu = mk3(cam.u[0], cam.u[1], cam.u[2]), ff = mk3(cam.f[0], cam.f[1], cam.f[2]);
+    rd = normalize(s * dc.x + uu * dc.y + (-ff) * dc.z);
+    ro = mk3(0, 0, 0) + rd * RAY_EPS;                                       // move_forward
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { T[i] = 1.0f; L[i] = 0.0f; }
+    from_camera = true; depth = 0; need_new = false;
+    if (STATS) st.samples++;
+    (void)need_new;
+}
+
+// One path vertex: the closest-hit result of P.ro/P.rd arrives (got/hit).  Accounts emission (with the strategy's weight),
+// applies throughput + Russian roulette, samples the BSDF and the light.  Returns true when the path ends here; otherwise
+// P.ro/P.rd hold the next ray.  `sh` receives the light connection (it may be set even when the path ends).
+template <bool STATS>
+PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, bool got, const Hit& hit, ShadowReq& sh,
+                         StatCounters& st, unsigned long long& tsa, unsigned long long& tsb) {
+    Sampler& smp = P.smp; Wl& wl = P.wl; float* T = P.T; float* L = P.L; f3& ro = P.ro; f3& rd = P.rd;
+    bool& from_camera = P.from_camera; bool& prev_spec = P.prev_spec; float* pf = P.pf; float& p_pdf = P.p_pdf; f3& prev_pos = P.prev_pos;
+    uint32_t& depth = P.depth;
+    bool end_path = false;
+    bool& do_shadow = sh.on; f3& sh_o = sh.o; f3& sh_d = sh.d; float& sh_t = sh.t; float* sh_c = sh.c;
+    do_shadow = false;
+
+    if (!got) {
+        end_path = true;   // no infinite lights in scope: radiance 0 (base_renderer.rs:180-186,240-253)
+    } else {
+        Surface sf = load_surface(sc, hit);
+        const DevMaterial* mat = sc.materials + sf.material;
+        const uint32_t mtype = mat->type;
+        const bool emissive = mtype == MT_EMISSIVE;
+        float Le[4] = {0, 0, 0, 0};
+        if (emissive) {                                                      // evaluate_emissive_surface :54-73
+            DevSpectrum rs = load_spectrum(&mat->color);
+            eval_spectrum<STATS>(sc, rs, wl, sf.uv, Le, st);
+            float inten = mat->intensity;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Le[i] = Le[i] * inten;
+        }
+        if (from_camera) {
+            if (emissive) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) L[i] = L[i] + T[i] * Le[i];      // :190-194
+            }
+        } else {
+            // calculate_bsdf_contribution (pt :33-47, nee :120-137, mis :151-181)
+            float tf = 1.0f / p_pdf;
+            if (emissive) {
+                float w = 1.0f;
+                if (prm.strategy == 1u) w = prev_spec ? 1.0f : 0.0f;
+                else if (prm.strategy == 2u && !prev_spec) {
+                    // Scene::pdf_light_sample (scene.rs:156-182); light probability = phi-weighted pick
+                    float wsum = 0.0f, wme = 0.0f;
+                    if (sc.n_lights == 1u) {
+                        // one light (every BASELINE config): phi(lambda) is Le * area, already evaluated
+                        // (emissive radiance cannot be a texture, so Le does not depend on uv)
+                        float sum = 0.0f;
+                        float area = sc.lights[0].area_sum;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += Le[i] * area;
+                        wsum = wme = sum / 4.0f;
+                    } else
+                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                        DevLight lt = sc.lights[li];
+                        const DevMaterial* lm = sc.materials + lt.material;
+                        float ph[4];
+                        DevSpectrum ls = load_spectrum(&lm->color);
+                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        float inten = lm->intensity;
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * inten) * lt.area_sum;
+                        float wt = sum / 4.0f;
+                        wsum += wt;
+                        if (li == sf.light) wme = wt;
+                    }
+                    float probability = wsum == 0.0f ? 0.0f : wme / wsum;
+                    f3 dv = prev_pos - sf.p;
+                    float distance = length(dv);
+                    f3 wo_l = -normalize(dv);
+                    float pdf_dir = sf.light_pdf_area * (distance * distance) / fabsf(dot(sf.ng, wo_l));
+                    w = balance_heuristic(p_pdf, probability * pdf_dir);
+                }
+                if (w != 0.0f || prm.strategy != 1u) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * ((pf[i] * Le[i]) * tf)) * w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) T[i] = T[i] * (pf[i] * tf);
+            // apply_russian_roulette (:76-92)
+            float p = fmaxf(fmaxf(fmaxf(fmaxf(-INFINITY, T[0]), T[1]), T[2]), T[3]);
+            if (!(p >= 1.0f)) {
+                float ur = get_1d(smp, sctx);
+                if (ur < p) {
+                    if (p != 0.0f) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) T[i] = T[i] / p;
+                    }
+                } else end_path = true;
+            }
+        }
+        if (!end_path) {
+            depth += 1;                                                       // for _ in 1..=max_depth (:197)
+            if (depth > prm.max_depth || emissive) end_path = true;           // as_bsdf_material() == None (:199-202)
+        }
+        if (!end_path) {
+            if (STATS) { st.bounces++; tsa = __builtin_amdgcn_s_memtime(); }
+            Frame fr = shading_frame(sf.ns, sf.tangent);
+            f3 wo_r = -rd;                                                    // Intersection.wo
+            f3 wo = to_local(fr, wo_r);
+            f3 ng_t = normalize(to_local(fr, sf.ng));                         // Transform * Normal renormalises
+            // base_renderer.rs:212-213 draws uc then uv for every material.  A draw whose value the material
+            // never reads only has to advance the sampler's dimension (Lambert ignores uc, lambert_material.rs:44;
+            // the smooth dielectric ignores uv, dielectric.rs:179-180): the Sobol digit loop is ~30 % of this
+            // kernel's VALU time, so unused values are not computed.
+            const bool is_diel = mtype == MT_GLASS || mtype == MT_PLASTIC;
+            float uc = 0.0f;
+            f2 uv = f2{0.0f, 0.0f};
+            if (is_diel) {
+                uc = get_1d(smp, sctx);
+                // Plastic indexes a *textured* colour with the random uv (plastic_material.rs:123-126, Q15)
+                if (mtype == MT_PLASTIC && mat->color.kind == SPK_TEXTURE) uv = get_2d(smp, sctx); else smp.dimension += 2;
+            }
+            else { smp.dimension += 1; uv = get_2d(smp, sctx); }
+            // normal map frame (identity without a normal texture)
+            Frame nf;
+            if (mat->normal_tex != 0xffffffffu) {
+                float rgb[3];
+                bilinear_rgb(sc, mat->normal_tex, sf.uv, rgb);                // normal_texture.rs:39-66
+                float nx = rgb[0] * 2.0f - 1.0f, ny = rgb[1] * 2.0f - 1.0f, nz = rgb[2] * 2.0f - 1.0f;
+                if (mat->normal_flip_y) ny = -ny;
+                float len = sqrtf(nx * nx + ny * ny + nz * nz);
+                f3 nm = mk3(0, 0, 1);
+                if (len > 0.0f) nm = normalize(normalize(mk3(nx / len, ny / len, nz / len)));
+                nf = normal_map_frame(nm);
+            } else {
+                nf.t = mk3(1, 0, 0); nf.b = mk3(0, 1, 0); nf.n = mk3(0, 0, 1);
+            }
+            f3 wo_nm = to_local(nf, wo);
+            bool sampled = false, specular = false;
+            f3 wi_sh = mk3(0, 0, 1);
+            float s_f[4] = {0, 0, 0, 0}, s_pdf = 0.0f;
+            float geo_wo = dot(ng_t, wo);
+
+            if (mtype == MT_LAMBERT) {
+                // LambertMaterial::sample (lambert_material.rs:42-97) + NormalizedLambertBsdf (lambert.rs:38-75)
+                float albedo[4];
+                DevSpectrum cs = load_spectrum(&mat->color);
+                eval_spectrum<STATS>(sc, cs, wl, sf.uv, albedo, st);
+                if (wo_nm.z != 0.0f) {
+                    float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
+                    f3 wi = mk3(r * cosf(th), r * sinf(th), sqrtf(1.0f - uv.x));
+                    if (wo_nm.z < 0.0f) wi.z = -wi.z;
+                    if (wi.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi.z)) {
+                        f3 w = to_world(nf, wi);
+                        float gwi = dot(ng_t, w);
+                        if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) {
+                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) / PI_F;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_f[i] = albedo[i] * fabsf(wi.z) / PI_F;
+                        }
+                    }
+                }
+                if (STATS) tsb = __builtin_amdgcn_s_memtime();
+                // NEE runs for every non-specular sample *including failed ones* (samples.rs:63-71, base_renderer.rs:218)
+                if (prm.strategy != 0u) {
+                    // light pick: LightSampler (light_sampler.rs:26-43,190-220)
+                    // with one light any u picks it (light_sampler.rs:31-42): only the dimension advances
+                    float ul = 0.0f;
+                    if (sc.n_lights == 1u) smp.dimension += 1; else ul = get_1d(smp, sctx);
+                    // phi-weighted light pick.  The picked light's radiance is evaluated ONCE and doubles as its
+                    // phi weight (emissive radiance is never a texture, so it does not depend on uv).
+                    uint32_t pick = 0; float wsum = 0.0f, wpick = 0.0f;
+                    float lrad[4];
+                    if (sc.n_lights == 1u) {
+                        const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
+                        DevSpectrum ls0 = load_spectrum(&lm0->color);
+                        eval_spectrum<STATS>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
+                        float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
+                        wsum = wpick = sum / 4.0f;
+                    } else {
+                        for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                            DevLight lt = sc.lights[li];
+                            const DevMaterial* lm = sc.materials + lt.material;
+                            float ph[4];
+                            DevSpectrum ls = load_spectrum(&lm->color);
+                            eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                            float sum = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                            wsum += sum / 4.0f;
+                        }
+                        float cum = 0.0f; bool chosen = false;
+                        pick = sc.n_lights - 1;
+                        for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                            DevLight lt = sc.lights[li];
+                            const DevMaterial* lm = sc.materials + lt.material;
+                            float ph[4];
+                            DevSpectrum ls = load_spectrum(&lm->color);
+                            eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                            float sum = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                            float wt = sum / 4.0f;
+                            cum += wt;
+                            if (!chosen && (ul < cum / wsum || li == sc.n_lights - 1)) {
+                                chosen = true; pick = li; wpick = wt;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) lrad[i] = ph[i];
+                            }
+                        }
+                    }
+                    if (sc.n_lights > 0 && wsum != 0.0f) {
+                        float lprob = wpick / wsum;
+                        float s1 = get_1d(smp, sctx);
+                        f2 luv = get_2d(smp, sctx);
+                        // EmissiveTriangleMesh::sample_radiance (emissive_triangle_mesh.rs:176-308)
+                        DevLight lt = sc.lights[pick];
+                        // first k with s < cdf[k] (else 0, :185-191).  The cdf is non-decreasing, so that index is the
+                        // number of entries <= s: independent loads instead of a chain of dependent ones.
+                        uint32_t cnt = 0;
+                        for (uint32_t k = 0; k < lt.n_tris; ++k) cnt += (s1 < sc.light_tris[lt.first_tri + k].cdf) ? 0u : 1u;
+                        uint32_t tsel = cnt < lt.n_tris ? cnt : 0u;
+                        const float4* q = (const float4*)(sc.light_tris + lt.first_tri + tsel);
+                        float4 qa = q[0], qb = q[1], qc = q[2];
+                        f3 p0 = mk3(qa.x, qa.y, qa.z), p1 = mk3(qa.w, qb.x, qb.y), p2 = mk3(qb.z, qb.w, qc.x);
+                        float b0, b1;
+                        if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
+                        float b2 = 1.0f - b0 - b1;
+                        f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
+                        f3 ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
+                        const DevMaterial* lm = sc.materials + lt.material;
+                        float pdf_a = 1.0f / lt.area_sum;
+                        f3 dv = lp - sf.p;
+                        f3 wi_r = normalize(dv);
+                        float distance = length(lp - sf.p);
+                        float pdf_dir = pdf_a * (distance * distance) / fmaxf(fabsf(dot(ln, -wi_r)), 1e-8f);
+                        // evaluate_area_light{,_with_mis} (common.rs:82-171)
+                        f3 wi_t = to_local(fr, wi_r);
+                        f3 wi_nm = to_local(nf, wi_t);
+                        float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
+                        float gwi = dot(ng_t, wi_t);
+                        if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
+                            pdf_b = fabsf(wi_nm.z) / PI_F;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) fl[i] = albedo[i] * fabsf(wi_nm.z) / PI_F;
+                        }
+                        float dist2 = dot(dv, dv);
+                        f3 ln_t = normalize(to_local(fr, ln));
+                        float g = fabsf(dot(ln_t, -wi_t)) / dist2;
+                        float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
+                        do_shadow = true;
+                        sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            sh_c[i] = (T[i] * ((fl[i] * (lrad[i] * lm->intensity)) * g / (pdf_a * lprob))) * wgt;
+                    }
+                }
+            } else if (mtype == MT_GLASS || mtype == MT_PLASTIC) {
+                // GlassMaterial/PlasticMaterial::sample -> DielectricBsdf::sample_specular (dielectric.rs:380-466)
+                float eta[4];
+                DevSpectrum es = load_spectrum(&mat->eta);
+                eval_spectrum<STATS>(sc, es, wl, sf.uv, eta, st);
+                bool eta_const = (eta[1] == eta[0]) && (eta[2] == eta[0]) && (eta[3] == eta[0]);
+                if (eta[0] == 0.0f) { eta[0] = eta[1] = eta[2] = eta[3] = 1.0f; eta_const = true; }   // DielectricBsdf::new :144-148
+                bool entering = geo_wo > 0.0f;
+                bool thin = mat->thin != 0;
+                if (wo_nm.z != 0.0f) {
+                    float er[4], fr4[4], favg;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) er[i] = (thin || entering) ? eta[i] : sdiv(1.0f, eta[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fr4[i] = fresnel_dielectric1(fabsf(wo_nm.z), er[i]);
+                    favg = (((0.0f + fr4[0]) + fr4[1]) + fr4[2] + fr4[3]) / 4.0f;
+                    float pr, pt;
+                    if (thin) {                                                   // calculate_thin_surface_coefficients :367-378
+                        float r = favg, t = 1.0f - r, r2 = r * r;
+                        pr = r2 > 1.0f ? 1.0f : r + (t * t * r) / (1.0f - r2);
+                        pt = t;
+                    } else { pr = favg; pt = 1.0f - pr; }
+                    f3 wi = mk3(0, 0, 1);
+                    if (uc < pr / (pr + pt)) {
+                        if (!(fabsf(wo_nm.z) < 1e-6f)) {
+                            sampled = true; specular = true; wi = mk3(-wo_nm.x, -wo_nm.y, wo_nm.z); s_pdf = pr / (pr + pt);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_f[i] = fr4[i];
+                        }
+                    } else if (thin) {
+                        wi = mk3(-wo_nm.x, -wo_nm.y, -wo_nm.z);
+                        if (wi.z != 0.0f) {
+                            sampled = true; specular = true; s_pdf = pt / (pr + pt);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_f[i] = 1.0f - fr4[i];
+                        }
+                    } else {
+                        if (!eta_const) wl.term = true;                           // terminate_secondary :446-448
+                        f3 n = entering ? mk3(0, 0, 1) : mk3(0, 0, -1);
+                        f3 wt;
+                        if (refract(wo_nm, n, er[0], wt) && wt.z != 0.0f) {
+                            sampled = true; specular = true; wi = wt; s_pdf = pt / (pr + pt);
+                            float e2 = er[0] * er[0];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_f[i] = sdiv(1.0f - fr4[i], e2);
+                        }
+                    }
+                    if (sampled) {
+                        if (mtype == MT_PLASTIC && dot(wi, wo_nm) < 0.0f) {          // plastic_material.rs:123-126 (random uv, Q15)
+                            float col[4];
+                            DevSpectrum cs = load_spectrum(&mat->color);
+                            eval_spectrum<STATS>(sc, cs, wl, uv, col, st);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_f[i] = s_f[i] * col[i];
+                        }
+                        wi_sh = to_world(nf, wi);
+                    }
+                }
+                // failed dielectric samples are "Diffuse" (non-specular): the reference then runs NEE with
+                // f == 0 and ends the path; nothing observable happens, so it is skipped here.
+            }
+
+            if (!sampled) {
+                end_path = true;                                              // process_bsdf_sampling -> None (:102-104,240-253)
+            } else {
+                // spawn the next ray (:106-121)
+                f3 wi_r = to_world(fr, wi_sh);
+                float sg = dot(sf.ng, wi_r) < 0.0f ? -1.0f : 1.0f;
+                f3 org = sf.p + (sg * sf.ng) * RAY_EPS;
+                rd = wi_r; ro = org + rd * RAY_EPS;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[i] = s_f[i];
+                p_pdf = s_pdf; prev_spec = specular; prev_pos = sf.p; from_camera = false;
+            }
+        }
+    }
+    return end_path;
+}
+
+struct PathOut { float* L; float* lam; float* pdf; };   // probe output (one path per lane)
+
+// Sensor::add_sample (sensor.rs:41-78): fold the finished path into the lane's film sums (or the probe output)
+template <bool PROBE>
+PT_DEV void film_add(const Path& P, const DevScene& sc, const DevParams& prm, float& acc_r, float& acc_g, float& acc_b, const PathOut& pout, uint32_t qi) {
+    const Wl& wl = P.wl; const float* L = P.L;
+    const float pdf0 = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
+
+    if (PROBE) {
+        
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pout.L[4 * qi + i] = L[i]; pout.lam[4 * qi + i] = wl.lam[i];
+            pout.pdf[4 * qi + i] = wl.term ? (i == 0 ? pdf0 / 4.0f : 0.0f) : pdf0;
+        }
+    } else {
+        float X = 0.0f, Y = 0.0f, Z = 0.0f;
+        const float4* cmf = (const float4*)sc.cmf;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k == 0 || !wl.term) {
+                int idx = (int)floorf(wl.lam[k] - LAMBDA_MIN);
+                if (idx == 470) idx = 0;
+                float pdf = wl.term ? pdf0 / 4.0f : pdf0;
+                float c = L[k] / pdf / 4.0f;
+                float4 m = cmf[idx];
+                X += c * m.x; Y += c * m.y; Z += c * m.z;
+            }
+        }
+        const float* M = prm.xyz_to_rgb;   // row-major; glam Mat3*Vec3 = col0*x + col1*y + col2*z
+        float r = M[0] * X + M[1] * Y + M[2] * Z;
+        float g = M[3] * X + M[4] * Y + M[5] * Z;
+        float b = M[6] * X + M[7] * Y + M[8] * Z;
+        acc_r += r * prm.exposure; acc_g += g * prm.exposure; acc_b += b * prm.exposure;
+    }
+}
+
+}  // namespace pt

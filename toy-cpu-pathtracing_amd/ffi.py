@@ -65,7 +65,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest",
                                           "nodes_shadow", "tris_shadow", "closest_hits", "bounces", "spectrum_evals",
-                                          "textured_lookups")] + [("phase_cycles", C.c_uint64 * 6), ("kernel_ms", C.c_double), ("launches", C.c_uint32)]
+                                          "textured_lookups")] + [("phase_cycles", C.c_uint64 * 10), ("kernel_ms", C.c_double), ("launches", C.c_uint32)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
