@@ -138,7 +138,7 @@ struct PathTracer {
 
     // evaluate_area_light{,_with_mis} (common.rs:82-171)
     void eval_area_light(const SurfaceInteraction& sp, const AreaSample& rad, const Material& mat, const Wavelengths& wl,
-                         V3 wo_render, const M4& r2t, float light_prob, bool mis, SS* contrib, float* weight, Counters* c) const {
+                         V3 wo_render, const M4& r2t, float light_prob, bool mis, SS* contrib, float* weight, Counters* c, uint64_t mc_key) const {
         V3 dv = rad.position - sp.position;
         Ray shadow = move_forward(Ray{sp.position, normalize(dv)}, SHADOW_EPS);
         float t = length(dv) - 2.0f * SHADOW_EPS;
@@ -149,6 +149,7 @@ struct PathTracer {
         V3 wi = transform_vector3(r2t, normalize(dv));
         ShadingPoint spt{transform_normal(r2t, sp.normal), sp.uv};
         MaterialEval me{scene, c};
+        me.mc_key = mc_key;   // same inner Monte-Carlo stream as the vertex's sample() call
         SS f = me.evaluate(mat, wl, wo, wi, spt);
         float distance2 = length_squared(dv);
         V3 ln = transform_normal(r2t, rad.light_normal);
@@ -186,6 +187,8 @@ struct PathTracer {
             ShadingPoint spt{transform_normal(r2t, hit.interaction.normal), hit.interaction.uv};
             float uc = smp.get_1d();
             V2 uv = smp.get_2d();
+            // key of the clearcoat's inner Monte-Carlo stream: one stream per path vertex (see McRng)
+            me.mc_key = mix_bits((((uint64_t)smp.morton_index) << 32) | (uint64_t)smp.dimension) ^ 0xD1B54A32D192ED03ull;
             MaterialSample ms = me.sample(mat, uc, uv, wl, wo, spt);
             if (ms.is_non_specular() && prm.strategy != STRAT_PT) {                         // base_renderer.rs:218-228
                 LightSampler ls(scene, wl);                                                 // mis_renderer.rs:40
@@ -196,7 +199,7 @@ struct PathTracer {
                     V2 luv = smp.get_2d();
                     AreaSample as = sample_area_light(lprim, hit.interaction.position, wl, s, luv, c);
                     SS contrib; float w;
-                    eval_area_light(hit.interaction, as, mat, wl, hit.wo, r2t, lprob, prm.strategy == STRAT_MIS, &contrib, &w, c);
+                    eval_area_light(hit.interaction, as, mat, wl, hit.wo, r2t, lprob, prm.strategy == STRAT_MIS, &contrib, &w, c, me.mc_key);
                     L = L + (T * contrib) * w;
                 }
             }

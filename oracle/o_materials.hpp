@@ -2,6 +2,7 @@
 // Restatement of scene/src/material/{common,edf}.rs, bsdf/{lambert,dielectric}.rs and
 // impls/{lambert,emissive,glass,plastic}_material.rs.
 #pragma once
+#include "o_sampler.hpp"
 #include "o_scene.hpp"
 
 namespace oracle {
@@ -253,6 +254,93 @@ struct DielectricBsdf {
     }
 };
 
+// ---------------- GeneralizedSchlickBsdf, ScatterMode::R (bsdf/generalized_schlick.rs) ----------------
+// The clearcoat material only ever instantiates it with ScatterMode::R, entering = true, thin = false
+// (simple_pbr_clearcoat_material.rs:121-133,445-456,...), so only the reflection arms are restated.
+struct McRng {              // stands in for rand::rng() inside directional_albedo (generalized_schlick.rs:901): a counter
+    uint64_t key; uint32_t n = 0;   // stream keyed per shading vertex, shared bit for bit with the HIP kernel
+    float next() { uint64_t h = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(++n)); return (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f; }
+};
+struct GenSchlickBsdf {
+    SS r0, r90; float exponent; SS tint; float ax, ay;
+    bool effectively_smooth() const { return std::fmax(ax, ay) < 1e-3f; }
+    SS fresnel(float cos_theta) const {                                       // :92-116
+        cos_theta = clampf(cos_theta, 0.0f, 1.0f);
+        float omc = 1.0f - cos_theta;
+        const float CMAX = 1.0f / 7.0f, OMCMAX = 1.0f - CMAX;
+        SS base = r0 + (r90 - r0) * std::pow(omc, exponent);
+        SS at_max = r0 + (r90 - r0) * std::pow(OMCMAX, exponent);
+        float om6 = OMCMAX * OMCMAX * OMCMAX * OMCMAX * OMCMAX * OMCMAX;     // powi(6)
+        SS a = at_max * (SS::one() - tint) / (CMAX * om6);
+        float o6 = omc * omc * omc * omc * omc * omc;
+        SS laz = a * cos_theta * o6;
+        return base - laz;
+    }
+    // same GGX helpers as DielectricBsdf (:119-210)
+    DielectricBsdf ggx() const { return DielectricBsdf(SS::one(), true, false, ax, ay); }
+    bool sample_R(V3 wo, V2 uv, BsdfSample* out) const {                       // sample(.., ScatterMode::R) :212-229,232-251,322-333
+        if (wo.z == 0.0f) return false;
+        if (effectively_smooth()) {
+            SS f = fresnel(std::fabs(wo.z));
+            V3 wi{-wo.x, -wo.y, wo.z};
+            if (wi.z == 0.0f) return false;
+            *out = BsdfSample{f, wi, 1.0f, ST_SPEC_REFL};
+            return true;
+        }
+        DielectricBsdf g = ggx();
+        V3 wm = g.sample_wm(wo, uv);
+        SS fr = fresnel(std::fabs(dot(wo, wm)));
+        V3 wi = reflect(wo, wm);                                              // sample_microfacet_reflection :342-372
+        if (!same_hemisphere(wo, wi)) return false;
+        float cd = std::fabs(dot(wo, wm));
+        if (cd < 1e-6f) return false;
+        float pdf = g.Dw(wo, wm) / (4.0f * cd) * 1.0f;
+        float d = g.D(wm), gg = g.G(wo, wi);
+        float ci = std::fabs(wi.z), co = std::fabs(wo.z);
+        if (ci == 0.0f || co == 0.0f) return false;
+        *out = BsdfSample{fr * d * gg / (4.0f * co), wi, pdf, ST_GLOSSY_REFL};
+        return true;
+    }
+    SS evaluate_R(V3 wo, V3 wi) const {                                        // :438-505
+        if (effectively_smooth()) return SS::zero();
+        float co = std::fabs(wo.z), ci = std::fabs(wi.z);
+        if (co == 0.0f || ci == 0.0f) return SS::zero();
+        if (!same_hemisphere(wo, wi)) return SS::zero();
+        V3 wm = wo + wi;                                                      // common.rs:47-57 half_vector
+        if (length_squared(wm) == 0.0f) return SS::zero();
+        wm = normalize(wm);
+        DielectricBsdf g = ggx();
+        SS fr = fresnel(std::fabs(dot(wo, wm)));
+        return fr * g.D(wm) * g.G(wo, wi) / (4.0f * co);
+    }
+    float pdf_R(V3 wo, V3 wi) const {                                          // :640-700,769-785
+        if (effectively_smooth()) return 0.0f;
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wm = wo + wi;
+        if (length_squared(wm) == 0.0f) return 0.0f;
+        wm = normalize(wm);
+        DielectricBsdf g = ggx();
+        float jac = 4.0f * std::fabs(dot(wo, wm));
+        if (jac == 0.0f) return 0.0f;
+        return g.Dw(wo, wm) / jac;
+    }
+    // directional_albedo (:893-918): 64-sample Monte Carlo of f * |cos_i| / pdf
+    SS directional_albedo(V3 wo, uint64_t key) const {
+        SS sum = SS::zero();
+        McRng rng{key};
+        for (int k = 0; k < 64; ++k) {
+            float uc = rng.next(); (void)uc;
+            V2 uv{0, 0}; uv.x = rng.next(); uv.y = rng.next();
+            BsdfSample s;
+            if (sample_R(wo, uv, &s)) {
+                float ci = std::fabs(s.wi.z);
+                if (ci > 0.0f && s.pdf > 0.0f) sum = sum + s.f * ci / s.pdf;
+            }
+        }
+        return sum / 64.0f;
+    }
+};
+
 // ---------------- material dispatch (BsdfSurfaceMaterial impls) ----------------
 struct ShadingPoint {   // SurfaceInteraction<VertexNormalTangent>
     V3 normal;          // geometric normal in the vertex-normal tangent frame
@@ -261,6 +349,7 @@ struct ShadingPoint {   // SurfaceInteraction<VertexNormalTangent>
 
 struct MaterialEval {
     const Scene& scene; Counters* ctr;
+    uint64_t mc_key = 0;   // per-vertex key of the clearcoat's inner Monte-Carlo stream (see McRng)
 
     M4 normal_map_transform(const Material& m, V2 uv) const {
         V3 nm = m.normal_tex >= 0 ? sample_normal_map(scene.textures[m.normal_tex], m.normal_flip_y, uv) : V3{0, 0, 1};
@@ -278,8 +367,93 @@ struct MaterialEval {
     }
 };
 
+// ---------------- SimpleClearcoatPbrMaterial (impls/simple_pbr_clearcoat_material.rs) ----------------
+struct Clearcoat {
+    const Material& m; SS base_color, tint; uint64_t key;
+    static float r2a(float r) { return r * r; }                                            // :76-78
+    static float diel_r0(float ior) { float r = (ior - 1.0f) / (ior + 1.0f); return r * r; }   // :81-84
+    static SS attenuation(SS tint, float thickness, float cos_theta) {                     // :88-107
+        SS log_tint = ss_log(tint);
+        SS sigma = (-1.0f * log_tint) / 0.001f;
+        float thickness_m = thickness * 0.001f;
+        float l = thickness_m / std::fmax(cos_theta, 1e-4f);
+        return ss_exp((-1.0f * sigma) * l);
+    }
+    GenSchlickBsdf coat() const { return GenSchlickBsdf{SS::constant(diel_r0(m.cc_ior)), SS::one(), 5.0f, SS::one(), r2a(m.cc_roughness), r2a(m.cc_roughness)}; }
+    GenSchlickBsdf metal(SS r0) const { float a = r2a(m.roughness); return GenSchlickBsdf{r0, SS::one(), 5.0f, SS::one(), a, a}; }
+    GenSchlickBsdf diel() const { float a = r2a(m.roughness); return GenSchlickBsdf{SS::constant(diel_r0(m.cc_base_ior)), SS::one(), 5.0f, SS::one(), a, a}; }
+
+    // sample_base_material (:336-383) in the normal-map frame; returns BsdfSample with wi in that frame
+    bool sample_metallic(V3 wo, V2 uv, BsdfSample* out) const { return metal(base_color).sample_R(wo, uv, out); }     // :455-493
+    bool sample_dielectric(V3 wo, float uc, V2 uv, BsdfSample* out) const {                                            // :494-551
+        GenSchlickBsdf g = diel();
+        float fr = g.fresnel(std::fabs(wo.z)).average();
+        if (uc < fr) {
+            BsdfSample b;
+            if (!g.sample_R(wo, uv, &b)) return false;
+            b.pdf = b.pdf * fr; *out = b; return true;
+        }
+        BsdfSample b;
+        if (!lambert_sample(base_color, wo, uv, &b)) return false;
+        b.f = b.f * (1.0f - fr); b.pdf = b.pdf * (1.0f - fr); *out = b; return true;
+    }
+    bool sample_base(V3 wo, float uc, V2 uv, BsdfSample* out) const {
+        if (m.cc_metallic >= 1.0f) return sample_metallic(wo, uv, out);
+        if (m.cc_metallic <= 0.0f) return sample_dielectric(wo, uc, uv, out);
+        if (uc <= m.cc_metallic) return sample_metallic(wo, uv, out);                                                  // sample_mixed :552-578
+        return sample_dielectric(wo, (uc - m.cc_metallic) / (1.0f - m.cc_metallic), uv, out);
+    }
+    SS eval_dielectric(V3 wo, V3 wi) const {                                                                            // :603-633
+        GenSchlickBsdf g = diel();
+        SS direct = g.evaluate_R(wo, wi);
+        float fr = g.fresnel(std::fabs(wo.z)).average();
+        return direct + (1.0f - fr) * lambert_evaluate(base_color, wo, wi);
+    }
+    SS eval_base(V3 wo, V3 wi) const {                                                                                  // :384-417
+        if (m.cc_metallic >= 1.0f) return metal(base_color).evaluate_R(wo, wi);
+        if (m.cc_metallic <= 0.0f) return eval_dielectric(wo, wi);
+        return metal(base_color).evaluate_R(wo, wi) * m.cc_metallic + eval_dielectric(wo, wi) * (1.0f - m.cc_metallic);
+    }
+    float pdf_dielectric(V3 wo, V3 wi) const {                                                                          // :646-675
+        GenSchlickBsdf g = diel();
+        float direct = g.pdf_R(wo, wi);
+        float fr = g.fresnel(std::fabs(wo.z)).average();
+        return fr * direct + (1.0f - fr) * lambert_pdf(wo, wi);
+    }
+    float pdf_base(V3 wo, V3 wi) const {                                                                                // :418-454
+        if (m.cc_metallic >= 1.0f) return metal(SS::one()).pdf_R(wo, wi);
+        if (m.cc_metallic <= 0.0f) return pdf_dielectric(wo, wi);
+        return metal(SS::one()).pdf_R(wo, wi) * m.cc_metallic + pdf_dielectric(wo, wi) * (1.0f - m.cc_metallic);
+    }
+    float coat_weight(V3 wo) const { return coat().directional_albedo(wo, key).average(); }                             // :190-192
+};
+
 inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, Wavelengths& wl, V3 wo, const ShadingPoint& sp) const {
     MaterialSample ms;
+    if (m.type == MAT_CLEARCOAT) {                                           // simple_pbr_clearcoat_material.rs:137-260
+        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key};
+        M4 tf = normal_map_transform(m, sp.uv);
+        M4 tf_inv = inverse(tf);
+        V3 wo_nm = transform_vector3(tf, wo);
+        BsdfSample bs;
+        if (m.cc_thickness <= 0.0f) {
+            if (!cc.sample_base(wo_nm, uc, uv, &bs)) return ms;
+            ms.f = bs.f; ms.wi = transform_vector3(tf_inv, bs.wi); ms.pdf = bs.pdf; ms.sample_type = bs.type; ms.is_sampled = true;
+            return ms;
+        }
+        float fc = cc.coat_weight(wo_nm);
+        if (uc < fc) {
+            if (!cc.coat().sample_R(wo_nm, uv, &bs)) return ms;
+            ms.f = bs.f; ms.wi = transform_vector3(tf_inv, bs.wi); ms.pdf = bs.pdf * fc; ms.sample_type = bs.type; ms.is_sampled = true;
+            return ms;
+        }
+        float uc_adj = (uc - fc) / (1.0f - fc);
+        if (!cc.sample_base(wo_nm, uc_adj, uv, &bs)) return ms;
+        V3 wi_sh = transform_vector3(tf_inv, bs.wi);
+        SS att = Clearcoat::attenuation(cc.tint, m.cc_thickness, wo_nm.z) * Clearcoat::attenuation(cc.tint, m.cc_thickness, wi_sh.z);   // Q14
+        ms.f = bs.f * att; ms.wi = wi_sh; ms.pdf = bs.pdf * (1.0f - fc); ms.sample_type = bs.type; ms.is_sampled = true;
+        return ms;
+    }
     if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:42-97
         SS albedo = scene.sample_spectrum_param(m.color, sp.uv, wl, ctr);
         M4 tf = normal_map_transform(m, sp.uv);
@@ -312,6 +486,17 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
 }
 
 inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const {
+    if (m.type == MAT_CLEARCOAT) {                                           // :261-341
+        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key};
+        M4 tf = normal_map_transform(m, sp.uv);
+        V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
+        if (m.cc_thickness <= 0.0f) return cc.eval_base(wo_nm, wi_nm);
+        float fc = cc.coat_weight(wo_nm);
+        SS cf = cc.coat().evaluate_R(wo_nm, wi_nm);
+        SS sf = cc.eval_base(wo_nm, wi_nm);
+        SS att = Clearcoat::attenuation(cc.tint, m.cc_thickness, wo_nm.z) * Clearcoat::attenuation(cc.tint, m.cc_thickness, wi_nm.z);
+        return cf * fc + sf * att * (1.0f - fc);
+    }
     if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:99-131
         SS albedo = scene.sample_spectrum_param(m.color, sp.uv, wl, ctr);
         M4 tf = normal_map_transform(m, sp.uv);
@@ -333,6 +518,14 @@ inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo
 }
 
 inline float MaterialEval::pdf(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const {
+    if (m.type == MAT_CLEARCOAT) {                                           // :342-433
+        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key};
+        M4 tf = normal_map_transform(m, sp.uv);
+        V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
+        if (m.cc_thickness <= 0.0f) return cc.pdf_base(wo_nm, wi_nm);
+        float fc = cc.coat_weight(wo_nm);
+        return cc.coat().pdf_R(wo_nm, wi_nm) * fc + cc.pdf_base(wo_nm, wi_nm) * (1.0f - fc);
+    }
     if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:133-159
         M4 tf = normal_map_transform(m, sp.uv);
         if (signum(dot(sp.normal, wi)) != signum(dot(sp.normal, wo))) return 0.0f;

@@ -139,7 +139,7 @@ def test_gpu_pt_nee_mis_consistency(product, pkg):
     assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
 
 
-@pytest.mark.parametrize("scene_id,strategy", [(8, "mis"), (10, "mis"), (0, "nee")])
+@pytest.mark.parametrize("scene_id,strategy", [(8, "mis"), (10, "mis"), (0, "nee"), (17, "nee"), (17, "mis")])
 def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     """Glass (scene 8: dispersive, wavelength termination), thin plastic (scene 10), plain Lambert (scene 0)."""
     pair = {}

@@ -242,6 +242,10 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
             if ((rc = im.lower_spectrum(d->color, &m.color, d->type == MI355PT_MAT_PLASTIC, &err))) return fail(rc, err);
             if (d->roughness >= 1e-3f) return fail(MI355PT_E_INVALID, "rough dielectrics are not implemented on the device yet (roughness must be < 1e-3)");
             break;
+        case MI355PT_MAT_CLEARCOAT:
+            if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, err);
+            if ((rc = im.lower_spectrum(d->clearcoat_tint, &m.cc_tint, true, &err))) return fail(rc, "clearcoat tint: " + err);
+            break;
         default:
             return fail(MI355PT_E_INVALID, "material type not implemented on the device yet");
     }

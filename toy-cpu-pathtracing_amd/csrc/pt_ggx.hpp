@@ -1,0 +1,126 @@
+// Trowbridge-Reitz (GGX) microfacet helpers, GeneralizedSchlickBsdf in ScatterMode::R and the
+// SimpleClearcoatPbrMaterial layering (scene/src/material/bsdf/generalized_schlick.rs,
+// scene/src/material/impls/simple_pbr_clearcoat_material.rs) for gfx950.
+// The clearcoat material only instantiates GeneralizedSchlick with mode R, entering, non-thin, tint = 1
+// (simple_pbr_clearcoat_material.rs:121-133,445-456,...), so only those arms exist here; with tint = 1 the
+// Lazanyi term of generalized_schlick.rs:104-114 is exactly zero.
+#pragma once
+#include "pt_device.hpp"
+
+namespace pt {
+
+PT_DEV float tan2_theta(f3 w) { float c2 = w.z * w.z; return c2 == 0.0f ? INFINITY : (1.0f - c2) / c2; }   // common.rs:19-26
+PT_DEV float cos_phi(f3 w) { float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f)); return st == 0.0f ? 1.0f : fminf(fmaxf(w.x / st, -1.0f), 1.0f); }
+PT_DEV float sin_phi(f3 w) { float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f)); return st == 0.0f ? 0.0f : fminf(fmaxf(w.y / st, -1.0f), 1.0f); }
+
+PT_DEV float ggx_D(float ax, float ay, f3 wm) {                                   // generalized_schlick.rs:119-131
+    float t2 = tan2_theta(wm);
+    if (!isfinite(t2)) return 0.0f;
+    float c2 = wm.z * wm.z, c4 = c2 * c2;
+    float cp = cos_phi(wm), sp = sin_phi(wm);
+    float e = t2 * ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay));
+    return 1.0f / (PI_F * ax * ay * c4 * ((1.0f + e) * (1.0f + e)));
+}
+PT_DEV float ggx_lambda(float ax, float ay, f3 w) {                               // :132-140
+    float t2 = tan2_theta(w);
+    if (isinf(t2)) return 0.0f;
+    float a = cos_phi(w) * ax, b = sin_phi(w) * ay;
+    return (sqrtf(1.0f + (a * a + b * b) * t2) - 1.0f) / 2.0f;
+}
+PT_DEV float ggx_G(float ax, float ay, f3 wo, f3 wi) { return 1.0f / (1.0f + ggx_lambda(ax, ay, wo) + ggx_lambda(ax, ay, wi)); }
+PT_DEV float ggx_Dw(float ax, float ay, f3 w, f3 wm) {                            // :154-164
+    float c = fabsf(w.z);
+    if (c == 0.0f) return 0.0f;
+    return (1.0f / (1.0f + ggx_lambda(ax, ay, w))) / c * ggx_D(ax, ay, wm) * fabsf(dot(w, wm));
+}
+PT_DEV f3 ggx_sample_wm(float ax, float ay, f3 w, f2 u) {                          // :165-199 (PBRT-v4 Sample_wm, polar disk)
+    f3 wh = normalize(mk3(ax * w.x, ay * w.y, w.z));
+    if (wh.z < 0.0f) wh = -wh;
+    f3 t1 = wh.z < 0.99999f ? normalize(cross(mk3(0, 0, 1), wh)) : mk3(1, 0, 0);
+    f3 t2 = cross(wh, t1);
+    float r = sqrtf(u.x), th = 2.0f * PI_F * u.y;
+    float px = r * cosf(th), pyy = r * sinf(th);
+    float h = sqrtf(fmaxf(1.0f - px * px, 0.0f));
+    float lf = (1.0f + wh.z) / 2.0f;
+    float py = h * (1.0f - lf) + pyy * lf;
+    float pz = sqrtf(fmaxf(1.0f - px * px - py * py, 0.0f));
+    f3 nh = t1 * px + t2 * py + wh * pz;
+    return normalize(mk3(ax * nh.x, ay * nh.y, fmaxf(1e-6f, nh.z)));
+}
+// generalized_schlick_fresnel with exponent 5, r90 = 1, tint = 1: r0 + (1 - r0) (1 - c)^5    (:92-116)
+PT_DEV float schlick_p5(float cos_theta) { float c = fminf(fmaxf(cos_theta, 0.0f), 1.0f); float o = 1.0f - c; float o2 = o * o; return o2 * o2 * o; }
+
+struct GsSample { f3 wi; float pdf; float dg; float p5; bool ok; bool specular; };   // f = F(p5) * dg
+// GeneralizedSchlickBsdf::sample(.., ScatterMode::R) minus the Fresnel colour (:212-251, 342-372):
+// returns wi, pdf, the colourless factor D*G/(4|cos o|) and (1-cos)^5 so the caller applies its r0.
+PT_DEV GsSample gs_sample_R(float alpha, f3 wo, f2 uv) {
+    GsSample s; s.ok = false; s.specular = false; s.wi = mk3(0, 0, 1); s.pdf = 0.0f; s.dg = 0.0f; s.p5 = 0.0f;
+    if (wo.z == 0.0f) return s;
+    if (alpha < 1e-3f) {                                                          // effectively_smooth -> sample_specular R
+        s.wi = mk3(-wo.x, -wo.y, wo.z);
+        if (s.wi.z == 0.0f) return s;
+        s.p5 = schlick_p5(fabsf(wo.z)); s.dg = 1.0f; s.pdf = 1.0f; s.ok = true; s.specular = true;
+        return s;
+    }
+    f3 wm = ggx_sample_wm(alpha, alpha, wo, uv);
+    float wodm = dot(wo, wm);
+    f3 wi = wm * (2.0f * wodm) - wo;                                              // reflect (common.rs:59-64)
+    if (!(wo.z * wi.z > 0.0f)) return s;
+    float cd = fabsf(wodm);
+    if (cd < 1e-6f) return s;
+    float ci = fabsf(wi.z), co = fabsf(wo.z);
+    float d = ggx_D(alpha, alpha, wm);
+    s.pdf = ggx_Dw(alpha, alpha, wo, wm) / (4.0f * cd) * 1.0f;
+    if (ci == 0.0f || co == 0.0f) return s;
+    s.dg = d * ggx_G(alpha, alpha, wo, wi) / (4.0f * co);
+    // note the reference multiplies (fresnel * d) * g / (4 co); the factor order differs by rounding only
+    s.p5 = schlick_p5(cd); s.wi = wi; s.ok = true;
+    return s;
+}
+// evaluate / pdf in mode R (:438-505, 640-700, 769-785): colourless factor + (1-cos)^5, and the pdf
+PT_DEV void gs_eval_R(float alpha, f3 wo, f3 wi, float& dg, float& p5, float& pdf) {
+    dg = 0.0f; p5 = 0.0f; pdf = 0.0f;
+    if (alpha < 1e-3f) return;
+    if (!(wo.z * wi.z > 0.0f)) return;                                            // same_hemisphere
+    f3 wm = wo + wi;
+    if (dot(wm, wm) == 0.0f) return;
+    wm = normalize(wm);
+    float co = fabsf(wo.z), ci = fabsf(wi.z);
+    float wodm = fabsf(dot(wo, wm));
+    float jac = 4.0f * wodm;
+    if (jac != 0.0f) pdf = ggx_Dw(alpha, alpha, wo, wm) / jac;
+    if (co == 0.0f || ci == 0.0f) return;
+    dg = ggx_D(alpha, alpha, wm) * ggx_G(alpha, alpha, wo, wi) / (4.0f * co);
+    p5 = schlick_p5(wodm);
+}
+
+// directional_albedo (:893-918): 64-sample Monte Carlo of f * |cos_i| / pdf for a *scalar* r0 (the coat).
+// The reference seeds it from the thread RNG on every call; here it is one counter stream per path vertex (key),
+// shared bit for bit with the oracle (oracle/o_materials.hpp McRng).
+PT_DEV float coat_directional_albedo(float alpha, float r0, f3 wo, uint64_t key) {
+    float sum = 0.0f;
+    uint32_t n = 0;
+    for (int k = 0; k < 64; ++k) {
+        n += 1;   // uc: drawn, unused in mode R
+        uint64_t h1 = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(++n));
+        uint64_t h2 = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(++n));
+        f2 uv = f2{(float)(uint32_t)(h1 >> 40) * 5.9604644775390625e-8f, (float)(uint32_t)(h2 >> 40) * 5.9604644775390625e-8f};
+        GsSample s = gs_sample_R(alpha, wo, uv);
+        if (s.ok) {
+            float ci = fabsf(s.wi.z);
+            float f = (r0 + (1.0f - r0) * s.p5) * s.dg;
+            if (ci > 0.0f && s.pdf > 0.0f) sum += f * ci / s.pdf;
+        }
+    }
+    return sum / 64.0f;
+}
+
+// compute_attenuation (simple_pbr_clearcoat_material.rs:88-107) for one wavelength lane
+PT_DEV float cc_attenuation1(float tint, float thickness, float cos_theta) {
+    float log_tint = logf(fmaxf(tint, 1e-10f));
+    float sigma = (-1.0f * log_tint) / 0.001f;
+    float l = (thickness * 0.001f) / fmaxf(cos_theta, 1e-4f);
+    return expf((-1.0f * sigma) * l);
+}
+
+}  // namespace pt

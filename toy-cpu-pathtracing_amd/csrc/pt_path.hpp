@@ -2,6 +2,7 @@
 // device functions shared by the kernel variants in pt_kernels.hip.  All state lives in registers.
 #pragma once
 #include "pt_device.hpp"
+#include "pt_ggx.hpp"
 
 namespace pt {
 
@@ -262,6 +263,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 // Plastic indexes a *textured* colour with the random uv (plastic_material.rs:123-126, Q15)
                 if (mtype == MT_PLASTIC && mat->color.kind == SPK_TEXTURE) uv = get_2d(smp, sctx); else smp.dimension += 2;
             }
+            else if (mtype == MT_CLEARCOAT) { uc = get_1d(smp, sctx); uv = get_2d(smp, sctx); }
             else { smp.dimension += 1; uv = get_2d(smp, sctx); }
             // normal map frame (identity without a normal texture)
             Frame nf;
@@ -283,9 +285,15 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
             float s_f[4] = {0, 0, 0, 0}, s_pdf = 0.0f;
             float geo_wo = dot(ng_t, wo);
 
+            // state the light connection needs to evaluate the BSDF again (BsdfSurfaceMaterial::{evaluate,pdf})
+            uint32_t nee_kind = 0;            // 0 none, 1 Lambert, 2 clearcoat
+            float albedo[4] = {0, 0, 0, 0};   // Lambert albedo / clearcoat base colour
+            float cc_tint[4] = {1, 1, 1, 1};
+            float cc_fc = 0.0f, cc_alpha_c = 0.0f, cc_alpha_b = 0.0f, cc_r0c = 0.0f, cc_r0d = 0.0f;
+
             if (mtype == MT_LAMBERT) {
                 // LambertMaterial::sample (lambert_material.rs:42-97) + NormalizedLambertBsdf (lambert.rs:38-75)
-                float albedo[4];
+                nee_kind = 1;
                 DevSpectrum cs = load_spectrum(&mat->color);
                 eval_spectrum<STATS>(sc, cs, wl, sf.uv, albedo, st);
                 if (wo_nm.z != 0.0f) {
@@ -300,103 +308,6 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
 #pragma unroll
                             for (int i = 0; i < 4; ++i) s_f[i] = albedo[i] * fabsf(wi.z) / PI_F;
                         }
-                    }
-                }
-                if (STATS) tsb = __builtin_amdgcn_s_memtime();
-                // NEE runs for every non-specular sample *including failed ones* (samples.rs:63-71, base_renderer.rs:218)
-                if (prm.strategy != 0u) {
-                    // light pick: LightSampler (light_sampler.rs:26-43,190-220)
-                    // with one light any u picks it (light_sampler.rs:31-42): only the dimension advances
-                    float ul = 0.0f;
-                    if (sc.n_lights == 1u) smp.dimension += 1; else ul = get_1d(smp, sctx);
-                    // phi-weighted light pick.  The picked light's radiance is evaluated ONCE and doubles as its
-                    // phi weight (emissive radiance is never a texture, so it does not depend on uv).
-                    uint32_t pick = 0; float wsum = 0.0f, wpick = 0.0f;
-                    float lrad[4];
-                    if (sc.n_lights == 1u) {
-                        const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
-                        DevSpectrum ls0 = load_spectrum(&lm0->color);
-                        eval_spectrum<STATS>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
-                        float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
-                        wsum = wpick = sum / 4.0f;
-                    } else {
-                        for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                            DevLight lt = sc.lights[li];
-                            const DevMaterial* lm = sc.materials + lt.material;
-                            float ph[4];
-                            DevSpectrum ls = load_spectrum(&lm->color);
-                            eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                            float sum = 0.0f;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
-                            wsum += sum / 4.0f;
-                        }
-                        float cum = 0.0f; bool chosen = false;
-                        pick = sc.n_lights - 1;
-                        for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                            DevLight lt = sc.lights[li];
-                            const DevMaterial* lm = sc.materials + lt.material;
-                            float ph[4];
-                            DevSpectrum ls = load_spectrum(&lm->color);
-                            eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                            float sum = 0.0f;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
-                            float wt = sum / 4.0f;
-                            cum += wt;
-                            if (!chosen && (ul < cum / wsum || li == sc.n_lights - 1)) {
-                                chosen = true; pick = li; wpick = wt;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) lrad[i] = ph[i];
-                            }
-                        }
-                    }
-                    if (sc.n_lights > 0 && wsum != 0.0f) {
-                        float lprob = wpick / wsum;
-                        float s1 = get_1d(smp, sctx);
-                        f2 luv = get_2d(smp, sctx);
-                        // EmissiveTriangleMesh::sample_radiance (emissive_triangle_mesh.rs:176-308)
-                        DevLight lt = sc.lights[pick];
-                        // first k with s < cdf[k] (else 0, :185-191).  The cdf is non-decreasing, so that index is the
-                        // number of entries <= s: independent loads instead of a chain of dependent ones.
-                        uint32_t cnt = 0;
-                        for (uint32_t k = 0; k < lt.n_tris; ++k) cnt += (s1 < sc.light_tris[lt.first_tri + k].cdf) ? 0u : 1u;
-                        uint32_t tsel = cnt < lt.n_tris ? cnt : 0u;
-                        const float4* q = (const float4*)(sc.light_tris + lt.first_tri + tsel);
-                        float4 qa = q[0], qb = q[1], qc = q[2];
-                        f3 p0 = mk3(qa.x, qa.y, qa.z), p1 = mk3(qa.w, qb.x, qb.y), p2 = mk3(qb.z, qb.w, qc.x);
-                        float b0, b1;
-                        if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
-                        float b2 = 1.0f - b0 - b1;
-                        f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
-                        f3 ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
-                        const DevMaterial* lm = sc.materials + lt.material;
-                        float pdf_a = 1.0f / lt.area_sum;
-                        f3 dv = lp - sf.p;
-                        f3 wi_r = normalize(dv);
-                        float distance = length(lp - sf.p);
-                        float pdf_dir = pdf_a * (distance * distance) / fmaxf(fabsf(dot(ln, -wi_r)), 1e-8f);
-                        // evaluate_area_light{,_with_mis} (common.rs:82-171)
-                        f3 wi_t = to_local(fr, wi_r);
-                        f3 wi_nm = to_local(nf, wi_t);
-                        float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
-                        float gwi = dot(ng_t, wi_t);
-                        if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
-                            pdf_b = fabsf(wi_nm.z) / PI_F;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) fl[i] = albedo[i] * fabsf(wi_nm.z) / PI_F;
-                        }
-                        float dist2 = dot(dv, dv);
-                        f3 ln_t = normalize(to_local(fr, ln));
-                        float g = fabsf(dot(ln_t, -wi_t)) / dist2;
-                        float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
-                        do_shadow = true;
-                        sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            sh_c[i] = (T[i] * ((fl[i] * (lrad[i] * lm->intensity)) * g / (pdf_a * lprob))) * wgt;
                     }
                 }
             } else if (mtype == MT_GLASS || mtype == MT_PLASTIC) {
@@ -459,6 +370,209 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 }
                 // failed dielectric samples are "Diffuse" (non-specular): the reference then runs NEE with
                 // f == 0 and ends the path; nothing observable happens, so it is skipped here.
+            }
+            else if (mtype == MT_CLEARCOAT) {
+                // SimpleClearcoatPbrMaterial::sample (simple_pbr_clearcoat_material.rs:137-260)
+                nee_kind = 2;
+                DevSpectrum cs = load_spectrum(&mat->color);
+                eval_spectrum<STATS>(sc, cs, wl, sf.uv, albedo, st);
+                DevSpectrum ts = load_spectrum(&mat->cc_tint);
+                eval_spectrum<STATS>(sc, ts, wl, sf.uv, cc_tint, st);
+                const float metallic = mat->metallic, thick = mat->cc_thickness;
+                cc_alpha_c = mat->cc_roughness * mat->cc_roughness;                 // roughness_to_alpha :76-78
+                cc_alpha_b = mat->roughness * mat->roughness;
+                { float r = (mat->cc_ior - 1.0f) / (mat->cc_ior + 1.0f); cc_r0c = r * r; }   // compute_dielectric_r0 :81-84
+                { float r = (mat->ior - 1.0f) / (mat->ior + 1.0f); cc_r0d = r * r; }
+                // coat weight: 64-sample Monte Carlo of the coat's directional albedo, ONE stream per path vertex.
+                // The reference re-draws it from the thread RNG in sample(), evaluate() and pdf() (:190-192,318-320,416-418);
+                // sharing one estimate per vertex keeps every marginal identical and is 3x cheaper.
+                uint64_t mc_key = mix_bits(((uint64_t)smp.morton << 32) | (uint64_t)smp.dimension) ^ 0xD1B54A32D192ED03ull;
+                if (thick > 0.0f) cc_fc = coat_directional_albedo(cc_alpha_c, cc_r0c, wo_nm, mc_key);
+                bool base = true;
+                float ucb = uc;
+                if (thick > 0.0f) {
+                    if (uc < cc_fc) {
+                        base = false;
+                        GsSample g = gs_sample_R(cc_alpha_c, wo_nm, uv);
+                        if (g.ok) {
+                            sampled = true; specular = g.specular; wi_sh = to_world(nf, g.wi); s_pdf = g.pdf * cc_fc;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_f[i] = (cc_r0c + (1.0f - cc_r0c) * g.p5) * g.dg;
+                        }
+                    } else ucb = (uc - cc_fc) / (1.0f - cc_fc);
+                }
+                if (base) {
+                    // sample_base_material (:336-383): metallic / dielectric(+Lambert) / mixed
+                    bool use_metal = metallic >= 1.0f || (metallic > 0.0f && ucb <= metallic);
+                    float ucd = (metallic > 0.0f && metallic < 1.0f) ? (ucb - metallic) / (1.0f - metallic) : ucb;
+                    f3 wi = mk3(0, 0, 1); bool okb = false; float fb[4] = {0, 0, 0, 0}, pb = 0.0f; bool specb = false;
+                    if (use_metal) {
+                        GsSample g = gs_sample_R(cc_alpha_b, wo_nm, uv);
+                        if (g.ok) {
+                            okb = true; wi = g.wi; pb = g.pdf; specb = g.specular;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) fb[i] = (albedo[i] + (1.0f - albedo[i]) * g.p5) * g.dg;
+                        }
+                    } else {
+                        float frd = cc_r0d + (1.0f - cc_r0d) * schlick_p5(fabsf(wo_nm.z));
+                        if (ucd < frd) {
+                            GsSample g = gs_sample_R(cc_alpha_b, wo_nm, uv);
+                            if (g.ok) {
+                                okb = true; wi = g.wi; pb = g.pdf * frd; specb = g.specular;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) fb[i] = (cc_r0d + (1.0f - cc_r0d) * g.p5) * g.dg;
+                            }
+                        } else if (wo_nm.z != 0.0f) {
+                            float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
+                            f3 w = mk3(r * cosf(th), r * sinf(th), sqrtf(1.0f - uv.x));
+                            if (wo_nm.z < 0.0f) w.z = -w.z;
+                            if (w.z != 0.0f && sgn1(wo_nm.z) == sgn1(w.z)) {
+                                okb = true; wi = w; pb = (fabsf(w.z) / PI_F) * (1.0f - frd);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) fb[i] = (albedo[i] * fabsf(w.z) / PI_F) * (1.0f - frd);
+                            }
+                        }
+                    }
+                    if (okb) {
+                        sampled = true; specular = specb; wi_sh = to_world(nf, wi);
+                        if (thick > 0.0f) {
+                            s_pdf = pb * (1.0f - cc_fc);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                s_f[i] = fb[i] * (cc_attenuation1(cc_tint[i], thick, wo_nm.z) * cc_attenuation1(cc_tint[i], thick, wi_sh.z));   // Q14
+                        } else {
+                            s_pdf = pb;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_f[i] = fb[i];
+                        }
+                    }
+                }
+            }
+
+            // a specular sample skips the light connection (base_renderer.rs:218); failed samples are 'Diffuse' and do not
+            if (specular) nee_kind = 0;
+            if (STATS) tsb = __builtin_amdgcn_s_memtime();
+            // NEE runs for every non-specular sample *including failed ones* (samples.rs:63-71, base_renderer.rs:218)
+            if (nee_kind != 0u && prm.strategy != 0u) {
+                // light pick: LightSampler (light_sampler.rs:26-43,190-220)
+                // with one light any u picks it (light_sampler.rs:31-42): only the dimension advances
+                float ul = 0.0f;
+                if (sc.n_lights == 1u) smp.dimension += 1; else ul = get_1d(smp, sctx);
+                // phi-weighted light pick.  The picked light's radiance is evaluated ONCE and doubles as its
+                // phi weight (emissive radiance is never a texture, so it does not depend on uv).
+                uint32_t pick = 0; float wsum = 0.0f, wpick = 0.0f;
+                float lrad[4];
+                if (sc.n_lights == 1u) {
+                    const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
+                    DevSpectrum ls0 = load_spectrum(&lm0->color);
+                    eval_spectrum<STATS>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
+                    float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
+                    wsum = wpick = sum / 4.0f;
+                } else {
+                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                        DevLight lt = sc.lights[li];
+                        const DevMaterial* lm = sc.materials + lt.material;
+                        float ph[4];
+                        DevSpectrum ls = load_spectrum(&lm->color);
+                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                        wsum += sum / 4.0f;
+                    }
+                    float cum = 0.0f; bool chosen = false;
+                    pick = sc.n_lights - 1;
+                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                        DevLight lt = sc.lights[li];
+                        const DevMaterial* lm = sc.materials + lt.material;
+                        float ph[4];
+                        DevSpectrum ls = load_spectrum(&lm->color);
+                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                        float wt = sum / 4.0f;
+                        cum += wt;
+                        if (!chosen && (ul < cum / wsum || li == sc.n_lights - 1)) {
+                            chosen = true; pick = li; wpick = wt;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lrad[i] = ph[i];
+                        }
+                    }
+                }
+                if (sc.n_lights > 0 && wsum != 0.0f) {
+                    float lprob = wpick / wsum;
+                    float s1 = get_1d(smp, sctx);
+                    f2 luv = get_2d(smp, sctx);
+                    // EmissiveTriangleMesh::sample_radiance (emissive_triangle_mesh.rs:176-308)
+                    DevLight lt = sc.lights[pick];
+                    // first k with s < cdf[k] (else 0, :185-191).  The cdf is non-decreasing, so that index is the
+                    // number of entries <= s: independent loads instead of a chain of dependent ones.
+                    uint32_t cnt = 0;
+                    for (uint32_t k = 0; k < lt.n_tris; ++k) cnt += (s1 < sc.light_tris[lt.first_tri + k].cdf) ? 0u : 1u;
+                    uint32_t tsel = cnt < lt.n_tris ? cnt : 0u;
+                    const float4* q = (const float4*)(sc.light_tris + lt.first_tri + tsel);
+                    float4 qa = q[0], qb = q[1], qc = q[2];
+                    f3 p0 = mk3(qa.x, qa.y, qa.z), p1 = mk3(qa.w, qb.x, qb.y), p2 = mk3(qb.z, qb.w, qc.x);
+                    float b0, b1;
+                    if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
+                    float b2 = 1.0f - b0 - b1;
+                    f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
+                    f3 ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
+                    const DevMaterial* lm = sc.materials + lt.material;
+                    float pdf_a = 1.0f / lt.area_sum;
+                    f3 dv = lp - sf.p;
+                    f3 wi_r = normalize(dv);
+                    float distance = length(lp - sf.p);
+                    float pdf_dir = pdf_a * (distance * distance) / fmaxf(fabsf(dot(ln, -wi_r)), 1e-8f);
+                    // evaluate_area_light{,_with_mis} (common.rs:82-171)
+                    f3 wi_t = to_local(fr, wi_r);
+                    f3 wi_nm = to_local(nf, wi_t);
+                    float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
+                    float gwi = dot(ng_t, wi_t);
+                    if (nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
+                        if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
+                            pdf_b = fabsf(wi_nm.z) / PI_F;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) fl[i] = albedo[i] * fabsf(wi_nm.z) / PI_F;
+                        }
+                    } else {                                                  // SimpleClearcoatPbrMaterial::{evaluate,pdf} (:261-433)
+                        float dgc, p5c, pdfc, dgb, p5b, pdfb;
+                        gs_eval_R(cc_alpha_c, wo_nm, wi_nm, dgc, p5c, pdfc);
+                        gs_eval_R(cc_alpha_b, wo_nm, wi_nm, dgb, p5b, pdfb);
+                        float metallic = mat->metallic;
+                        // Lambert lobe of the dielectric base (lambert.rs:77-120)
+                        float lam_f = 0.0f, lam_pdf = 0.0f;
+                        if (wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) { lam_f = fabsf(wi_nm.z) / PI_F; lam_pdf = lam_f; }
+                        float frd = cc_r0d + (1.0f - cc_r0d) * schlick_p5(fabsf(wo_nm.z));     // fresnel(wo).average(), scalar r0
+                        float pdf_met = pdfb, pdf_die = frd * pdfb + (1.0f - frd) * lam_pdf;
+                        float pdf_base = metallic >= 1.0f ? pdf_met : (metallic <= 0.0f ? pdf_die : pdf_met * metallic + pdf_die * (1.0f - metallic));
+                        float thick = mat->cc_thickness;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float f_met = (albedo[i] + (1.0f - albedo[i]) * p5b) * dgb;
+                            float f_die = (cc_r0d + (1.0f - cc_r0d) * p5b) * dgb + (1.0f - frd) * (albedo[i] * lam_f);
+                            float f_base = metallic >= 1.0f ? f_met : (metallic <= 0.0f ? f_die : f_met * metallic + f_die * (1.0f - metallic));
+                            if (thick <= 0.0f) fl[i] = f_base;
+                            else {
+                                float att = cc_attenuation1(cc_tint[i], thick, wo_nm.z) * cc_attenuation1(cc_tint[i], thick, wi_nm.z);
+                                fl[i] = ((cc_r0c + (1.0f - cc_r0c) * p5c) * dgc) * cc_fc + f_base * att * (1.0f - cc_fc);
+                            }
+                        }
+                        pdf_b = thick <= 0.0f ? pdf_base : pdfc * cc_fc + pdf_base * (1.0f - cc_fc);
+                    }
+                    float dist2 = dot(dv, dv);
+                    f3 ln_t = normalize(to_local(fr, ln));
+                    float g = fabsf(dot(ln_t, -wi_t)) / dist2;
+                    float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
+                    do_shadow = true;
+                    sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        sh_c[i] = (T[i] * ((fl[i] * (lrad[i] * lm->intensity)) * g / (pdf_a * lprob))) * wgt;
+                }
             }
 
             if (!sampled) {
