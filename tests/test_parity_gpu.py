@@ -159,6 +159,12 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     close = np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)
     assert close.mean() >= 0.98, close.mean()
     assert abs(Lg[:, 0].mean() - Lc[:, 0].mean()) <= 0.02 * Lc[:, 0].mean()
+    # the render path uses a kernel specialised for the scene's materials (probes use the all-features build):
+    # compare a small image too (reference metric, regression_test.rs:6-40)
+    prm8 = pkg.make_params(8, strategy, "sobol")
+    qg = product.quantize_u8(product.render(pair["gpu"][0], pair["gpu"][1], prm8))
+    qc = oracle.quantize_u8(oracle.render(pair["cpu"][0], pair["cpu"][1], prm8))
+    assert linear_rmse_u8(qg, qc) <= 0.01
 
 
 def test_shards_tile_the_frame(product, pkg):

@@ -12,7 +12,7 @@
 #include "scene.hpp"
 
 namespace pt {
-hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, unsigned*, DevStats*, bool, int, hipStream_t);
+hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, unsigned*, DevStats*, bool, uint32_t, int, hipStream_t);
 hipError_t launch_probe_radiance(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, unsigned*, const uint32_t*, uint32_t, float*,
                                  float*, float*, int, hipStream_t);
 hipError_t launch_resolve(const float*, uint32_t, uint32_t, float*, hipStream_t);
@@ -298,7 +298,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (stats) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
     int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)waves);
-    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, d_counter, d_stats, want_stats, grid, stream));
+    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, d_counter, d_stats, want_stats, s->impl.features, grid, stream));
     if (stats) {
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(hipEventSynchronize(e1));

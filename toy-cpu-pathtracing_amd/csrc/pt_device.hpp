@@ -256,12 +256,12 @@ struct StatCounters {
 };
 
 // SpectrumParameter::sample(uv).sample(lambda)  (parameter.rs:38-47, spectrum.rs:32-46)
-template <bool STATS>
+template <bool STATS, bool TEX = true>
 PT_DEV void eval_spectrum(const DevScene& sc, const DevSpectrum& sp, const Wl& w, f2 uv, float out[4], StatCounters& st) {
     if (STATS) st.spectrum_evals++;
     float c0 = sp.c[0], c1 = sp.c[1], c2 = sp.c[2];
     uint32_t kind = sp.kind;
-    if (kind == SPK_TEXTURE) {
+    if (TEX && kind == SPK_TEXTURE) {
         if (STATS) st.textured_lookups++;
         float rgb[3], c[3];
         bilinear_rgb(sc, sp.id, uv, rgb);

@@ -82,7 +82,7 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 // ------------------------------------------------------------------------------------------------------------------
 // Variant 1: lock-step wave.  Every iteration all lanes trace one closest ray, shade, trace one shadow ray.
 // ------------------------------------------------------------------------------------------------------------------
-template <bool STATS, bool PROBE>
+template <bool STATS, bool PROBE, uint32_t FEAT>
 __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, unsigned* __restrict__ work_counter,
                                                 DevStats* __restrict__ stats, const uint32_t* __restrict__ probe_xys, uint32_t n_probe,
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
             if (STATS) ts2 = __builtin_amdgcn_s_memtime();
             bool end_path = false;
             ShadowReq sh{};
-            if (active) end_path = shade_vertex<STATS>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
+            if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
             if (STATS) ts3 = __builtin_amdgcn_s_memtime();
             if (sh.on) {
                 bool occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st);
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
 // ------------------------------------------------------------------------------------------------------------------
 enum : uint32_t { LS_NEW = 0, LS_END = 1, LS_SHADE = 2, LS_TRAV = 3, LS_DONE = 4 };
 
-template <bool STATS, bool PROBE>
+template <bool STATS, bool PROBE, uint32_t FEAT>
 __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, unsigned* __restrict__ work_counter,
                                                 DevStats* __restrict__ stats, const uint32_t* __restrict__ probe_xys, uint32_t n_probe,
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
                 if (stage == LS_NEW) { regen_path<STATS>(P, sctx, cam, job.px, job.py, s_cur, st); start_closest = true; }
                 else if (stage == LS_SHADE) {
                     ShadowReq sh{};
-                    bool end_path = shade_vertex<STATS>(P, sc, prm, sctx, found, hit, sh, st, tsa, tsb);
+                    bool end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, found, hit, sh, st, tsa, tsb);
                     if (sh.on) {
                         t_ro = sh.o; t_rd = sh.d; rs = setup_ray(t_rd); t_best = sh.t;
                         cur = sc.root; sp = 0; found = false; t_shadow = true; t_fin = false;
@@ -411,17 +411,34 @@ __global__ __launch_bounds__(64) void probe_occluded_kernel(DevScene sc, const f
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (host side, called from api.cpp)
 // ---------------------------------------------------------------------------------------------
+// smallest compiled specialisation covering `feat`
+static uint32_t pick_features(uint32_t feat) {
+    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_CC, FEAT_ALL};
+    for (uint32_t s : sets) if ((feat & ~s) == 0u) return s;
+    return FEAT_ALL;
+}
+#define PT_LAUNCH(F) hipLaunchKernelGGL((pt_kernel<false, false, F>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_counter, d_stats, nullptr, 0u, po)
 hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const uint64_t* d_hash, float* d_accum,
-                     unsigned* d_counter, DevStats* d_stats, bool stats, int grid, hipStream_t stream) {
+                     unsigned* d_counter, DevStats* d_stats, bool stats, uint32_t feat, int grid, hipStream_t stream) {
     PathOut po{nullptr, nullptr, nullptr};
-    if (stats) hipLaunchKernelGGL((pt_kernel<true, false>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_counter, d_stats, nullptr, 0u, po);
-    else hipLaunchKernelGGL((pt_kernel<false, false>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_counter, d_stats, nullptr, 0u, po);
+    if (stats) {
+        hipLaunchKernelGGL((pt_kernel<true, false, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_counter, d_stats, nullptr, 0u, po);
+        return hipGetLastError();
+    }
+    switch (pick_features(feat)) {
+        case 0u: PT_LAUNCH(0u); break;
+        case FEAT_TEX: PT_LAUNCH(FEAT_TEX); break;
+        case FEAT_DIEL: PT_LAUNCH(FEAT_DIEL); break;
+        case FEAT_CC: PT_LAUNCH(FEAT_CC); break;
+        default: PT_LAUNCH(FEAT_ALL); break;
+    }
     return hipGetLastError();
 }
+#undef PT_LAUNCH
 hipError_t launch_probe_radiance(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const uint64_t* d_hash, unsigned* d_counter,
                                  const uint32_t* d_xys, uint32_t n, float* d_L, float* d_lam, float* d_pdf, int grid, hipStream_t stream) {
     PathOut po{d_L, d_lam, d_pdf};
-    hipLaunchKernelGGL((pt_kernel<false, true>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, nullptr, d_counter, nullptr, d_xys, n, po);
+    hipLaunchKernelGGL((pt_kernel<false, true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, nullptr, d_counter, nullptr, d_xys, n, po);
     return hipGetLastError();
 }
 hipError_t launch_resolve(const float* d_accum, uint32_t n_values, uint32_t spp, float* d_out, hipStream_t stream) {
@@ -454,7 +471,7 @@ int query_resident_waves() {
     if (hipGetDevice(&dev) != hipSuccess) return 2048;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false>, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_ALL>, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
     return prop.multiProcessorCount * per_cu;
 }
 }  // namespace pt

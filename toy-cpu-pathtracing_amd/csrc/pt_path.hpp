@@ -153,7 +153,7 @@ PT_DEV void regen_path(Path& P, const SamplerCtx& sctx, const DevCamera& cam, ui
 // One path vertex: the closest-hit result of P.ro/P.rd arrives (got/hit).  Accounts emission (with the strategy's weight),
 // applies throughput + Russian roulette, samples the BSDF and the light.  Returns true when the path ends here; otherwise
 // P.ro/P.rd hold the next ray.  `sh` receives the light connection (it may be set even when the path ends).
-template <bool STATS>
+template <bool STATS, uint32_t FEAT>
 PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, bool got, const Hit& hit, ShadowReq& sh,
                          StatCounters& st, unsigned long long& tsa, unsigned long long& tsb) {
     Sampler& smp = P.smp; Wl& wl = P.wl; float* T = P.T; float* L = P.L; f3& ro = P.ro; f3& rd = P.rd;
@@ -173,7 +173,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
         float Le[4] = {0, 0, 0, 0};
         if (emissive) {                                                      // evaluate_emissive_surface :54-73
             DevSpectrum rs = load_spectrum(&mat->color);
-            eval_spectrum<STATS>(sc, rs, wl, sf.uv, Le, st);
+            eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, rs, wl, sf.uv, Le, st);
             float inten = mat->intensity;
 #pragma unroll
             for (int i = 0; i < 4; ++i) Le[i] = Le[i] * inten;
@@ -192,7 +192,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 else if (prm.strategy == 2u && !prev_spec) {
                     // Scene::pdf_light_sample (scene.rs:156-182); light probability = phi-weighted pick
                     float wsum = 0.0f, wme = 0.0f;
-                    if (sc.n_lights == 1u) {
+                    if (!(FEAT & FEAT_MLIGHT) || sc.n_lights == 1u) {
                         // one light (every BASELINE config): phi(lambda) is Le * area, already evaluated
                         // (emissive radiance cannot be a texture, so Le does not depend on uv)
                         float sum = 0.0f;
@@ -206,7 +206,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float inten = lm->intensity;
                         float sum = 0.0f;
 #pragma unroll
@@ -255,7 +255,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
             // never reads only has to advance the sampler's dimension (Lambert ignores uc, lambert_material.rs:44;
             // the smooth dielectric ignores uv, dielectric.rs:179-180): the Sobol digit loop is ~30 % of this
             // kernel's VALU time, so unused values are not computed.
-            const bool is_diel = mtype == MT_GLASS || mtype == MT_PLASTIC;
+            const bool is_diel = (FEAT & FEAT_DIEL) && (mtype == MT_GLASS || mtype == MT_PLASTIC);
             float uc = 0.0f;
             f2 uv = f2{0.0f, 0.0f};
             if (is_diel) {
@@ -263,11 +263,11 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 // Plastic indexes a *textured* colour with the random uv (plastic_material.rs:123-126, Q15)
                 if (mtype == MT_PLASTIC && mat->color.kind == SPK_TEXTURE) uv = get_2d(smp, sctx); else smp.dimension += 2;
             }
-            else if (mtype == MT_CLEARCOAT) { uc = get_1d(smp, sctx); uv = get_2d(smp, sctx); }
+            else if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) { uc = get_1d(smp, sctx); uv = get_2d(smp, sctx); }
             else { smp.dimension += 1; uv = get_2d(smp, sctx); }
             // normal map frame (identity without a normal texture)
             Frame nf;
-            if (mat->normal_tex != 0xffffffffu) {
+            if ((FEAT & FEAT_TEX) && mat->normal_tex != 0xffffffffu) {
                 float rgb[3];
                 bilinear_rgb(sc, mat->normal_tex, sf.uv, rgb);                // normal_texture.rs:39-66
                 float nx = rgb[0] * 2.0f - 1.0f, ny = rgb[1] * 2.0f - 1.0f, nz = rgb[2] * 2.0f - 1.0f;
@@ -295,7 +295,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 // LambertMaterial::sample (lambert_material.rs:42-97) + NormalizedLambertBsdf (lambert.rs:38-75)
                 nee_kind = 1;
                 DevSpectrum cs = load_spectrum(&mat->color);
-                eval_spectrum<STATS>(sc, cs, wl, sf.uv, albedo, st);
+                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
                 if (wo_nm.z != 0.0f) {
                     float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
                     f3 wi = mk3(r * cosf(th), r * sinf(th), sqrtf(1.0f - uv.x));
@@ -310,11 +310,11 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         }
                     }
                 }
-            } else if (mtype == MT_GLASS || mtype == MT_PLASTIC) {
+            } else if (is_diel) {
                 // GlassMaterial/PlasticMaterial::sample -> DielectricBsdf::sample_specular (dielectric.rs:380-466)
                 float eta[4];
                 DevSpectrum es = load_spectrum(&mat->eta);
-                eval_spectrum<STATS>(sc, es, wl, sf.uv, eta, st);
+                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, es, wl, sf.uv, eta, st);
                 bool eta_const = (eta[1] == eta[0]) && (eta[2] == eta[0]) && (eta[3] == eta[0]);
                 if (eta[0] == 0.0f) { eta[0] = eta[1] = eta[2] = eta[3] = 1.0f; eta_const = true; }   // DielectricBsdf::new :144-148
                 bool entering = geo_wo > 0.0f;
@@ -361,7 +361,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         if (mtype == MT_PLASTIC && dot(wi, wo_nm) < 0.0f) {          // plastic_material.rs:123-126 (random uv, Q15)
                             float col[4];
                             DevSpectrum cs = load_spectrum(&mat->color);
-                            eval_spectrum<STATS>(sc, cs, wl, uv, col, st);
+                            eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, uv, col, st);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) s_f[i] = s_f[i] * col[i];
                         }
@@ -371,13 +371,13 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 // failed dielectric samples are "Diffuse" (non-specular): the reference then runs NEE with
                 // f == 0 and ends the path; nothing observable happens, so it is skipped here.
             }
-            else if (mtype == MT_CLEARCOAT) {
+            else if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) {
                 // SimpleClearcoatPbrMaterial::sample (simple_pbr_clearcoat_material.rs:137-260)
                 nee_kind = 2;
                 DevSpectrum cs = load_spectrum(&mat->color);
-                eval_spectrum<STATS>(sc, cs, wl, sf.uv, albedo, st);
+                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
                 DevSpectrum ts = load_spectrum(&mat->cc_tint);
-                eval_spectrum<STATS>(sc, ts, wl, sf.uv, cc_tint, st);
+                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ts, wl, sf.uv, cc_tint, st);
                 const float metallic = mat->metallic, thick = mat->cc_thickness;
                 cc_alpha_c = mat->cc_roughness * mat->cc_roughness;                 // roughness_to_alpha :76-78
                 cc_alpha_b = mat->roughness * mat->roughness;
@@ -457,15 +457,15 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 // light pick: LightSampler (light_sampler.rs:26-43,190-220)
                 // with one light any u picks it (light_sampler.rs:31-42): only the dimension advances
                 float ul = 0.0f;
-                if (sc.n_lights == 1u) smp.dimension += 1; else ul = get_1d(smp, sctx);
+                if (!(FEAT & FEAT_MLIGHT) || sc.n_lights == 1u) smp.dimension += 1; else ul = get_1d(smp, sctx);
                 // phi-weighted light pick.  The picked light's radiance is evaluated ONCE and doubles as its
                 // phi weight (emissive radiance is never a texture, so it does not depend on uv).
                 uint32_t pick = 0; float wsum = 0.0f, wpick = 0.0f;
                 float lrad[4];
-                if (sc.n_lights == 1u) {
+                if (!(FEAT & FEAT_MLIGHT) || sc.n_lights == 1u) {
                     const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
                     DevSpectrum ls0 = load_spectrum(&lm0->color);
-                    eval_spectrum<STATS>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
+                    eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
                     float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
@@ -476,7 +476,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
@@ -489,7 +489,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
@@ -532,7 +532,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     f3 wi_nm = to_local(nf, wi_t);
                     float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
                     float gwi = dot(ng_t, wi_t);
-                    if (nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
+                    if (!(FEAT & FEAT_CC) || nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
                         if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
                             pdf_b = fabsf(wi_nm.z) / PI_F;
 #pragma unroll

@@ -262,6 +262,13 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     dev.n_nodes = (uint32_t)bvh.nodes.size(); dev.n_tris = (uint32_t)tris.size();
     dev.n_lights = (uint32_t)lights.size(); dev.n_materials = (uint32_t)materials.size();
     dev.root = bvh.root;
+    features = lights.size() == 1 ? 0u : FEAT_MLIGHT;
+    for (const HostInstance& inst : instances) {
+        const DevMaterial& m = materials[inst.mat];
+        if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL;
+        if (m.type == MT_CLEARCOAT) features |= FEAT_CC;
+        if (m.normal_tex != 0xffffffffu || m.color.kind == SPK_TEXTURE || m.cc_tint.kind == SPK_TEXTURE) features |= FEAT_TEX;
+    }
     info = "nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth);
     built = true;
     return MI355PT_OK;

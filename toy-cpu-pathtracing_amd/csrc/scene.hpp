@@ -49,6 +49,7 @@ struct SceneImpl {
     std::vector<void*> allocs;
     uint32_t cmf_lut[3] = {0, 0, 0};
     int bvh_depth = 0;
+    uint32_t features = FEAT_ALL;   // FEAT_* bits the scene's materials need (kernel specialisation)
     std::string info;
 
     ~SceneImpl();
