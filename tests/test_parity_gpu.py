@@ -3,6 +3,8 @@
 Bars: integer work (Sobol) bit-exact; floating point within the tolerances written in each test
 (BASELINE north_star: "output matches ... within a stated per-pixel L2 tolerance, Sobol bit-exact vs CPU").
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -178,3 +180,31 @@ def test_shards_tile_the_frame(product, pkg):
     nz = [(p != 0).any(axis=2) for p in parts]
     assert not (nz[0] & nz[1]).any() and not (nz[0] & nz[2]).any() and not (nz[1] & nz[2]).any()
     assert np.array_equal(sum(parts), full)
+
+
+def test_cpp_host_cli_matches_python_binding(product, pkg, tmp_path):
+    """The C++ mirror of the reference's renderer API (toy-cpu-pathtracing_amd/host: Scene::load_obj, load_scene_3,
+    RendererImage::render/save, main.rs flags) must produce the picture the ctypes path produces: same library, same
+    assets through OBJ/PPM files instead of arrays."""
+    import subprocess, sys
+    from PIL import Image
+    root = pkg.ffi.ROOT
+    exe = os.path.join(root, "toy-cpu-pathtracing_amd", "host", "mi355pt")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    assets_dir = str(tmp_path / "assets")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "export_assets.py"), assets_dir])
+    for scene_id, renderer in ((3, "mis"), (17, "nee")):
+        out = str(tmp_path / f"cli_{scene_id}.png")
+        env = dict(os.environ, MI355PT_ASSETS=assets_dir, MI355PT_DATA=os.path.join(root, "toy-cpu-pathtracing_amd", "data"))
+        r = subprocess.run([exe, "--scene", str(scene_id), "--renderer", renderer, "--sampler", "sobol", "--spp", "8", "--width", "96",
+                            "--height", "64", "--output", out], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Finish rendering" in r.stdout
+        cli = np.asarray(Image.open(out).convert("RGB"))
+        sc = product.new_scene()
+        cam = pkg.scenes.load_scene(sc, scene_id, 96, 64)
+        ref = product.quantize_u8(product.render(sc, cam, pkg.make_params(8, renderer, "sobol")))
+        assert cli.shape == ref.shape
+        assert (np.abs(cli.astype(int) - ref.astype(int)) <= 1).mean() >= 0.999
+        assert linear_rmse_u8(cli, ref) <= 1e-3

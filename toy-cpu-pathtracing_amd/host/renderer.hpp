@@ -1,0 +1,388 @@
+// C++ host side above the C ABI: mirrors the reference's Rust API for the hot path so that scene files and a
+// main() read like the reference's (the reference is Rust; no Rust toolchain exists in this image — DESIGN.md §1).
+//
+//   reference (Rust)                                             here (C++)
+//   scene::Scene / create_scene!()   scene/src/scene.rs:36-76    renderer::Scene
+//   Scene::load_obj                  scene.rs:47-49              Scene::load_obj   (tobj single_index + triangulate semantics)
+//   Scene::create_primitive          scene.rs:57-61              Scene::create_primitive(GeometryPrimitive{..})
+//   Scene::build(&camera)            scene.rs:64-76              Scene::build(camera)
+//   LambertMaterial::new ...         material/impls/*.rs         LambertMaterial::create ... (value types, no Arc)
+//   SpectrumParameter / NormalParameter / FloatParameter         same names
+//   RgbTexture::load_srgb, NormalTexture::load                   same names (8-bit binary PPM "P6" files instead of PNG)
+//   presets::cie_illum_d6500(), glass_sf11_eta()                 presets::... (baked 470-entry LUTs, data/presets470.bin)
+//   Camera::new + set_look_to        renderer/src/camera.rs      renderer::Camera
+//   RendererArgs, SrgbRenderer{Pt,Nee,Mis}, RendererImage        same names; RendererImage::render(sampler) calls mi355pt_render
+//   RendererImage::save              renderer.rs:137-148         same truncating quantisation, PNG written without zlib
+//
+// Error behaviour: the reference panics; this layer throws std::runtime_error carrying mi355pt_last_error().
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/mi355pt.h"
+
+namespace renderer {
+
+inline void check(int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + mi355pt_last_error());
+}
+
+struct Vec3 { float x, y, z; };
+
+// ------------------------------------------------------------------ data directory
+inline std::string data_dir() {
+    const char* e = std::getenv("MI355PT_DATA");
+    return e ? e : "toy-cpu-pathtracing_amd/data";
+}
+
+// ------------------------------------------------------------------ spectra
+struct Spectrum { mi355pt_spectrum s{}; std::vector<float> lut; };   // lut non-empty => registered lazily per scene
+
+struct ColorSrgb { float r, g, b; };
+struct RgbAlbedoSpectrum {                                            // spectrum/src/spectrum/rgb_albedo_spectrum.rs:21-27
+    static Spectrum create(ColorSrgb c) { Spectrum s; s.s.kind = MI355PT_SPEC_RGB_ALBEDO_SRGB; s.s.c[0] = c.r; s.s.c[1] = c.g; s.s.c[2] = c.b; return s; }
+};
+struct ConstantSpectrum {
+    static Spectrum create(float v) { Spectrum s; s.s.kind = MI355PT_SPEC_CONSTANT; s.s.c[0] = v; return s; }
+};
+namespace presets {
+inline Spectrum load(const std::string& name) {
+    std::ifstream js(data_dir() + "/presets470.json");
+    if (!js) throw std::runtime_error("presets470.json not found under " + data_dir());
+    std::stringstream ss; ss << js.rdbuf();
+    std::string txt = ss.str();
+    // names are listed in file order inside "names": [...]
+    std::vector<std::string> names;
+    size_t lb = txt.find('[', txt.find("\"names\""));
+    size_t rb = txt.find(']', lb);
+    for (size_t pos = lb;;) {
+        size_t q0 = txt.find('"', pos);
+        if (q0 == std::string::npos || q0 > rb) break;
+        size_t q1 = txt.find('"', q0 + 1);
+        names.push_back(txt.substr(q0 + 1, q1 - q0 - 1));
+        pos = q1 + 1;
+    }
+    for (size_t i = 0; i < names.size(); ++i)
+        if (names[i] == name) {
+            std::ifstream bin(data_dir() + "/presets470.bin", std::ios::binary);
+            bin.seekg((std::streamoff)(i * 470 * sizeof(float)));
+            Spectrum s; s.s.kind = MI355PT_SPEC_LUT470; s.lut.resize(470);
+            bin.read((char*)s.lut.data(), 470 * sizeof(float));
+            if (!bin) throw std::runtime_error("presets470.bin truncated");
+            return s;
+        }
+    throw std::runtime_error("unknown preset spectrum " + name);
+}
+inline Spectrum cie_illum_d6500() { return load("cie_illum_d6500"); }   // spectrum/src/presets.rs:310-312
+inline Spectrum glass_sf11_eta() { return load("glass_sf11_eta"); }     // :458-460
+inline Spectrum glass_bk7_eta() { return load("glass_bk7_eta"); }
+}  // namespace presets
+
+// ------------------------------------------------------------------ textures (scene/src/texture/*.rs)
+struct ImageRgb8 { std::vector<uint8_t> rgb; uint32_t w = 0, h = 0; };
+inline ImageRgb8 load_ppm(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open texture " + path);
+    std::string magic; f >> magic;
+    if (magic != "P6") throw std::runtime_error(path + ": expected a binary PPM (P6)");
+    auto skip = [&]() { while (true) { int c = f.peek(); if (c == '#') { std::string l; std::getline(f, l); } else if (isspace(c)) f.get(); else break; } };
+    ImageRgb8 im; int maxv;
+    skip(); f >> im.w; skip(); f >> im.h; skip(); f >> maxv; f.get();
+    if (maxv != 255) throw std::runtime_error(path + ": only 8-bit PPM supported");
+    im.rgb.resize((size_t)im.w * im.h * 3);
+    f.read((char*)im.rgb.data(), (std::streamsize)im.rgb.size());
+    if (!f) throw std::runtime_error(path + ": truncated");
+    return im;
+}
+struct RgbTexture { std::shared_ptr<ImageRgb8> img; static RgbTexture load_srgb(const std::string& p) { return {std::make_shared<ImageRgb8>(load_ppm(p))}; } };
+struct NormalTexture { std::shared_ptr<ImageRgb8> img; bool flip_y; static NormalTexture load(const std::string& p, bool flip_y) { return {std::make_shared<ImageRgb8>(load_ppm(p)), flip_y}; } };
+enum class SpectrumType { Albedo };
+
+// ------------------------------------------------------------------ parameters (scene/src/material/parameter.rs)
+struct SpectrumParameter {
+    bool is_texture = false; Spectrum spectrum; RgbTexture tex;
+    static SpectrumParameter constant(Spectrum s) { SpectrumParameter p; p.spectrum = std::move(s); return p; }
+    static SpectrumParameter texture(RgbTexture t, SpectrumType) { SpectrumParameter p; p.is_texture = true; p.tex = std::move(t); return p; }
+};
+struct FloatParameter { float v; static FloatParameter constant(float x) { return {x}; } };
+struct NormalParameter {
+    bool has = false; NormalTexture tex{};
+    static NormalParameter none() { return {}; }
+    static NormalParameter texture(NormalTexture t) { NormalParameter p; p.has = true; p.tex = std::move(t); return p; }
+};
+
+// ------------------------------------------------------------------ materials (scene/src/material/impls/*.rs)
+struct Material {
+    uint32_t type = 0; SpectrumParameter color; NormalParameter normal; float intensity = 1; Spectrum eta; bool thin = false; float roughness = 0;
+    float metallic = 0, ior = 1.5f, clearcoat_ior = 1.5f, clearcoat_roughness = 0, clearcoat_thickness = 0; SpectrumParameter clearcoat_tint;
+};
+struct LambertMaterial { static Material create(SpectrumParameter albedo, NormalParameter n) { Material m; m.type = MI355PT_MAT_LAMBERT; m.color = std::move(albedo); m.normal = std::move(n); return m; } };
+struct EmissiveMaterial { static Material create(SpectrumParameter radiance, FloatParameter intensity) { Material m; m.type = MI355PT_MAT_EMISSIVE; m.color = std::move(radiance); m.intensity = intensity.v; return m; } };
+enum class GlassType { Bk7, Sf11 };
+struct GlassMaterial {
+    static Material create(GlassType t, NormalParameter n, bool thin, FloatParameter rough) {
+        Material m; m.type = MI355PT_MAT_GLASS; m.eta = t == GlassType::Sf11 ? presets::glass_sf11_eta() : presets::glass_bk7_eta();
+        m.color = SpectrumParameter::constant(ConstantSpectrum::create(1.0f)); m.normal = std::move(n); m.thin = thin; m.roughness = rough.v; return m;
+    }
+};
+struct PlasticMaterial {
+    static Material create(float eta, SpectrumParameter color, NormalParameter n, bool thin, FloatParameter rough) {
+        Material m; m.type = MI355PT_MAT_PLASTIC; m.eta = ConstantSpectrum::create(eta); m.color = std::move(color); m.normal = std::move(n); m.thin = thin; m.roughness = rough.v; return m;
+    }
+};
+struct SimpleClearcoatPbrMaterial {
+    static Material create(SpectrumParameter base_color, FloatParameter metallic, FloatParameter roughness, NormalParameter n, FloatParameter ior,
+                           FloatParameter cc_ior, FloatParameter cc_rough, SpectrumParameter cc_tint, FloatParameter cc_thickness) {
+        Material m; m.type = MI355PT_MAT_CLEARCOAT; m.color = std::move(base_color); m.metallic = metallic.v; m.roughness = roughness.v; m.normal = std::move(n);
+        m.ior = ior.v; m.clearcoat_ior = cc_ior.v; m.clearcoat_roughness = cc_rough.v; m.clearcoat_tint = std::move(cc_tint); m.clearcoat_thickness = cc_thickness.v; return m;
+    }
+};
+
+// ------------------------------------------------------------------ Transform (math/src/transform.rs:76-162), column-major glam::Mat4
+struct Transform {
+    float m[16];
+    static Transform identity() { Transform t{}; for (int i = 0; i < 16; ++i) t.m[i] = (i % 5 == 0) ? 1.0f : 0.0f; return t; }
+    static Transform mul(const Transform& a, const Transform& b) {
+        Transform o{};
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) {
+            float s = a.m[r] * b.m[4 * c]; s = s + a.m[4 + r] * b.m[4 * c + 1]; s = s + a.m[8 + r] * b.m[4 * c + 2]; s = s + a.m[12 + r] * b.m[4 * c + 3];
+            o.m[4 * c + r] = s;
+        }
+        return o;
+    }
+    Transform rotate_y(float angle_rad) const {      // .rotate(Quat::from_euler(XYZ, 0, a, 0)) — left-multiplies (:134-137)
+        // glam: q = (0, sin(a/2), 0, cos(a/2)); Mat4::from_quat builds 1 - y*(y+y) and w*(y+y)
+        float y = std::sin(angle_rad * 0.5f), w = std::cos(angle_rad * 0.5f);
+        float y2 = y + y, yy = y * y2, wy = w * y2;
+        Transform r = identity();
+        r.m[0] = 1.0f - yy; r.m[2] = -wy; r.m[8] = wy; r.m[10] = 1.0f - yy;
+        return mul(r, *this);
+    }
+    Transform scale(Vec3 v) const { Transform s = identity(); s.m[0] = v.x; s.m[5] = v.y; s.m[10] = v.z; return mul(s, *this); }
+    Transform translate(Vec3 v) const { Transform t = identity(); t.m[12] = v.x; t.m[13] = v.y; t.m[14] = v.z; return mul(t, *this); }
+};
+
+// ------------------------------------------------------------------ Camera (renderer/src/camera.rs:14-92)
+class Camera {
+public:
+    Camera(float fov, uint32_t width, uint32_t height) { c_.fov_deg = fov; c_.width = width; c_.height = height; set_look_to({0, 0, 0}, {0, 0, -1}, {0, 1, 0}); }
+    void set_look_to(Vec3 p, Vec3 d, Vec3 u) {
+        c_.position[0] = p.x; c_.position[1] = p.y; c_.position[2] = p.z; c_.direction[0] = d.x; c_.direction[1] = d.y; c_.direction[2] = d.z;
+        c_.up[0] = u.x; c_.up[1] = u.y; c_.up[2] = u.z;
+    }
+    const mi355pt_camera& raw() const { return c_; }
+private:
+    mi355pt_camera c_{};
+};
+
+// ------------------------------------------------------------------ OBJ loading (geometry/impls/triangle_mesh.rs:141-242)
+struct TriangleMeshData { std::vector<float> pos, nrm, uv, tangent; std::vector<uint32_t> idx; };
+inline Vec3 v_sub(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 v_cross(Vec3 a, Vec3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline float v_dot(Vec3 a, Vec3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+inline Vec3 v_norm(Vec3 a) { float r = 1.0f / std::sqrt(v_dot(a, a)); return {a.x * r, a.y * r, a.z * r}; }
+inline bool v_nan(Vec3 a) { return std::isnan(a.x) || std::isnan(a.y) || std::isnan(a.z); }
+
+inline TriangleMeshData load_obj_file(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot open OBJ " + path);
+    std::vector<Vec3> v, vn; std::vector<std::array<float, 2>> vt;
+    std::map<std::tuple<int, int, int>, uint32_t> remap;      // tobj single_index: one vertex per distinct (v, vt, vn)
+    TriangleMeshData out;
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream ls(line);
+        std::string tag; ls >> tag;
+        if (tag == "v") { Vec3 p; ls >> p.x >> p.y >> p.z; v.push_back(p); }
+        else if (tag == "vn") { Vec3 p; ls >> p.x >> p.y >> p.z; vn.push_back(p); }
+        else if (tag == "vt") { std::array<float, 2> t; ls >> t[0] >> t[1]; vt.push_back(t); }
+        else if (tag == "f") {
+            std::vector<uint32_t> face;
+            std::string tok;
+            while (ls >> tok) {
+                int a = 0, b = 0, c = 0;
+                if (std::sscanf(tok.c_str(), "%d/%d/%d", &a, &b, &c) == 3) {}
+                else if (std::sscanf(tok.c_str(), "%d//%d", &a, &c) == 2) { b = 0; }
+                else if (std::sscanf(tok.c_str(), "%d/%d", &a, &b) == 2) { c = 0; }
+                else { std::sscanf(tok.c_str(), "%d", &a); }
+                auto key = std::make_tuple(a, b, c);
+                auto it = remap.find(key);
+                if (it == remap.end()) {
+                    uint32_t id = (uint32_t)(out.pos.size() / 3);
+                    Vec3 p = v.at((size_t)a - 1);
+                    out.pos.insert(out.pos.end(), {p.x, p.y, p.z});
+                    if (c > 0) { Vec3 n = vn.at((size_t)c - 1); out.nrm.insert(out.nrm.end(), {n.x, n.y, n.z}); }
+                    if (b > 0) { auto t = vt.at((size_t)b - 1); out.uv.insert(out.uv.end(), {t[0], t[1]}); }
+                    it = remap.emplace(key, id).first;
+                }
+                face.push_back(it->second);
+            }
+            for (size_t k = 1; k + 1 < face.size(); ++k) { out.idx.push_back(face[0]); out.idx.push_back(face[k]); out.idx.push_back(face[k + 1]); }   // triangulate
+        }
+    }
+    if (out.nrm.size() != out.pos.size()) throw std::runtime_error(path + ": every vertex needs a normal");
+    if (!out.uv.empty() && out.uv.size() / 2 != out.pos.size() / 3) throw std::runtime_error(path + ": inconsistent texcoords");
+    // per-triangle tangents with the reference's fallback rules (:181-226)
+    if (!out.uv.empty()) {
+        auto P = [&](uint32_t i) { return Vec3{out.pos[3 * i], out.pos[3 * i + 1], out.pos[3 * i + 2]}; };
+        auto fallback = [](Vec3 e1, Vec3 e2) {
+            Vec3 c = v_cross(e1, e2);
+            if (v_dot(c, c) < 1e-12f) return Vec3{1, 0, 0};
+            Vec3 n = v_norm(v_norm(c));
+            Vec3 cand = std::fabs(n.x) > 0.999f ? Vec3{0, 1, 0} : Vec3{1, 0, 0};
+            float pm = v_dot(n, cand);
+            return v_norm(Vec3{cand.x - n.x * pm, cand.y - n.y * pm, cand.z - n.z * pm});
+        };
+        for (size_t t = 0; t < out.idx.size() / 3; ++t) {
+            uint32_t i0 = out.idx[3 * t], i1 = out.idx[3 * t + 1], i2 = out.idx[3 * t + 2];
+            Vec3 e1 = v_sub(P(i1), P(i0)), e2 = v_sub(P(i2), P(i0));
+            float du1 = out.uv[2 * i1] - out.uv[2 * i0], dv1 = out.uv[2 * i1 + 1] - out.uv[2 * i0 + 1];
+            float du2 = out.uv[2 * i2] - out.uv[2 * i0], dv2 = out.uv[2 * i2 + 1] - out.uv[2 * i0 + 1];
+            float den = du1 * dv2 - dv1 * du2;
+            float r = 1.0f / den;
+            Vec3 tg{r * (e1.x * dv2 - e2.x * dv1), r * (e1.y * dv2 - e2.y * dv1), r * (e1.z * dv2 - e2.z * dv1)};
+            if (std::fabs(den) < 1e-6f) tg = fallback(e1, e2);
+            else { tg = v_norm(tg); if (v_nan(tg)) tg = fallback(e1, e2); }
+            out.tangent.insert(out.tangent.end(), {tg.x, tg.y, tg.z});
+        }
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------ Scene
+struct GeometryIndex { uint32_t id; };
+struct GeometryPrimitive { GeometryIndex geometry_index; Material surface_material; Transform transform; };   // CreatePrimitiveDesc::GeometryPrimitive
+
+class Scene {
+public:
+    Scene() {
+        check(mi355pt_scene_create(&s_), "mi355pt_scene_create");
+        std::ifstream t(data_dir() + "/srgb_table.bin", std::ios::binary);
+        if (!t) throw std::runtime_error("srgb_table.bin not found under " + data_dir() + " (run __graft_entry__.build())");
+        std::vector<float> tab(64 + 3 * 64 * 64 * 64 * 3);
+        t.read((char*)tab.data(), (std::streamsize)(tab.size() * sizeof(float)));
+        check(mi355pt_scene_set_rgb2spec(s_, tab.data(), tab.size()), "mi355pt_scene_set_rgb2spec");
+    }
+    ~Scene() { mi355pt_scene_destroy(s_); }
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+
+    GeometryIndex load_obj(const std::string& path) {
+        TriangleMeshData m = load_obj_file(path);
+        uint32_t id;
+        check(mi355pt_scene_add_mesh(s_, m.pos.data(), m.nrm.data(), m.uv.empty() ? nullptr : m.uv.data(), m.tangent.empty() ? nullptr : m.tangent.data(),
+                                     m.idx.data(), (uint32_t)(m.pos.size() / 3), (uint32_t)(m.idx.size() / 3), &id), "mi355pt_scene_add_mesh");
+        return {id};
+    }
+    void create_primitive(const GeometryPrimitive& d) {
+        mi355pt_material_desc md{};
+        const Material& m = d.surface_material;
+        md.type = m.type; md.color = lower(m.color); md.normal_tex = MI355PT_NONE;
+        if (m.normal.has) { md.normal_tex = add_tex(*m.normal.tex.img); md.normal_flip_y = m.normal.tex.flip_y ? 1 : 0; }
+        md.intensity = m.intensity; md.thin = m.thin ? 1 : 0; md.roughness = m.roughness;
+        if (m.type == MI355PT_MAT_GLASS || m.type == MI355PT_MAT_PLASTIC) md.eta = lower_spectrum(m.eta);
+        md.metallic = m.metallic; md.ior = m.ior; md.clearcoat_ior = m.clearcoat_ior; md.clearcoat_roughness = m.clearcoat_roughness;
+        md.clearcoat_thickness = m.clearcoat_thickness;
+        if (m.type == MI355PT_MAT_CLEARCOAT) md.clearcoat_tint = lower(m.clearcoat_tint);
+        uint32_t mat;
+        check(mi355pt_scene_add_material(s_, &md, &mat), "mi355pt_scene_add_material");
+        check(mi355pt_scene_add_instance(s_, d.geometry_index.id, mat, d.transform.m), "mi355pt_scene_add_instance");
+    }
+    void build(const Camera& cam) { check(mi355pt_scene_build(s_, &cam.raw()), "mi355pt_scene_build"); }
+    const mi355pt_scene* raw() const { return s_; }
+
+private:
+    uint32_t add_tex(const ImageRgb8& im) { uint32_t id; check(mi355pt_scene_add_tex_rgb8(s_, im.rgb.data(), im.w, im.h, &id), "mi355pt_scene_add_tex_rgb8"); return id; }
+    mi355pt_spectrum lower_spectrum(const Spectrum& sp) {
+        mi355pt_spectrum s = sp.s;
+        if (s.kind == MI355PT_SPEC_LUT470) check(mi355pt_scene_add_lut470(s_, sp.lut.data(), &s.id), "mi355pt_scene_add_lut470");
+        return s;
+    }
+    mi355pt_spectrum lower(const SpectrumParameter& p) {
+        if (!p.is_texture) return lower_spectrum(p.spectrum);
+        mi355pt_spectrum s{}; s.kind = MI355PT_SPEC_TEXTURE_ALBEDO_SRGB; s.id = add_tex(*p.tex.img); return s;
+    }
+    mi355pt_scene* s_ = nullptr;
+};
+
+// ------------------------------------------------------------------ renderers (renderer/src/renderer.rs:84-149, main.rs:142-237)
+enum class SamplerKind { Random = MI355PT_SAMPLER_RANDOM, ZSobol = MI355PT_SAMPLER_SOBOL };
+struct RendererArgs { uint32_t width, height, spp, seed; const Scene* scene; const Camera* camera; };
+struct SrgbRenderer { RendererArgs args; uint32_t strategy; float exposure; uint32_t max_depth; };
+inline SrgbRenderer SrgbRendererPt(RendererArgs a, float exposure, uint32_t max_depth) { return {a, MI355PT_STRATEGY_PT, exposure, max_depth}; }
+inline SrgbRenderer SrgbRendererNee(RendererArgs a, float exposure, uint32_t max_depth) { return {a, MI355PT_STRATEGY_NEE, exposure, max_depth}; }
+inline SrgbRenderer SrgbRendererMis(RendererArgs a, float exposure, uint32_t max_depth) { return {a, MI355PT_STRATEGY_MIS, exposure, max_depth}; }
+
+class RendererImage {
+public:
+    RendererImage(uint32_t w, uint32_t h, SrgbRenderer r) : pixels_((size_t)w * h * 3, 0.0f), w_(w), h_(h), r_(r) {}
+    // RendererImage::render::<S>() — the seam: one call into the HIP library fills `pixels`
+    double render(SamplerKind sampler) {
+        mi355pt_params p{};
+        p.spp = r_.args.spp; p.seed = r_.args.seed; p.max_depth = r_.max_depth; p.strategy = r_.strategy; p.sampler = (uint32_t)sampler;
+        p.exposure = r_.exposure; p.shard_index = 0; p.shard_count = 1;
+        mi355pt_stats st{};
+        check(mi355pt_render(r_.args.scene->raw(), &r_.args.camera->raw(), &p, pixels_.data(), &st), "mi355pt_render");
+        return st.kernel_ms * 1e-3;
+    }
+    const std::vector<float>& pixels() const { return pixels_; }
+    // RendererImage::save (renderer.rs:137-148): (p*255.0) as u8, PNG
+    void save(const std::string& path) const;
+private:
+    std::vector<float> pixels_; uint32_t w_, h_; SrgbRenderer r_;
+};
+
+// ------------------------------------------------------------------ minimal PNG writer (stored deflate blocks, no zlib dependency)
+inline uint32_t crc32_of(const uint8_t* d, size_t n, uint32_t crc = 0) {
+    static uint32_t table[256]; static bool init = false;
+    if (!init) { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; } init = true; }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ d[i]) & 0xff] ^ (crc >> 8);
+    return ~crc;
+}
+inline void write_png_rgb8(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t h) {
+    std::vector<uint8_t> raw; raw.reserve((size_t)(w * 3 + 1) * h);
+    for (uint32_t y = 0; y < h; ++y) { raw.push_back(0); raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3); }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
+    for (size_t off = 0; off < raw.size(); off += 65535) {
+        size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back(n & 0xff); z.push_back((n >> 8) & 0xff); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + (std::ptrdiff_t)off, raw.begin() + (std::ptrdiff_t)(off + n));
+    }
+    uint32_t adler = (b << 16) | a;
+    for (int i = 3; i >= 0; --i) z.push_back((adler >> (8 * i)) & 0xff);
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot write " + path);
+    auto be32 = [](uint32_t v, uint8_t* o) { o[0] = v >> 24; o[1] = (v >> 16) & 0xff; o[2] = (v >> 8) & 0xff; o[3] = v & 0xff; };
+    auto chunk = [&](const char* tag, const std::vector<uint8_t>& data) {
+        uint8_t len[4]; be32((uint32_t)data.size(), len); f.write((char*)len, 4);
+        std::vector<uint8_t> td(tag, tag + 4); td.insert(td.end(), data.begin(), data.end());
+        f.write((char*)td.data(), (std::streamsize)td.size());
+        uint8_t crc[4]; be32(crc32_of(td.data(), td.size()), crc); f.write((char*)crc, 4);
+    };
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    f.write((const char*)sig, 8);
+    std::vector<uint8_t> ihdr(13); be32(w, &ihdr[0]); be32(h, &ihdr[4]); ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk("IHDR", ihdr); chunk("IDAT", z); chunk("IEND", {});
+}
+inline void RendererImage::save(const std::string& path) const {
+    std::vector<uint8_t> q(pixels_.size());
+    check(mi355pt_quantize_u8(pixels_.data(), pixels_.size(), q.data()), "mi355pt_quantize_u8");
+    write_png_rgb8(path, q.data(), w_, h_);
+}
+
+}  // namespace renderer

@@ -83,8 +83,11 @@ def _room(scene, p, with_box=True):
 def _mat4_trs_scene17():
     """Transform::identity().rotate(Quat::from_euler(XYZ, 0, 120deg, 0)).scale(2.5).translate(0,0,0.5)
     = T * S * R  (scene_17.rs:61-69, transform.rs:128-145), float32."""
-    a = np.float32(np.deg2rad(np.float32(120.0)))
-    c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+    a = np.float32(np.float32(120.0) * np.float32(np.pi / 180.0))          # f32::to_radians
+    # glam: q = (0, sin(a/2), 0, cos(a/2)); Mat4::from_quat builds 1 - y*(y+y) and w*(y+y)
+    y, w = np.float32(np.sin(a * np.float32(0.5))), np.float32(np.cos(a * np.float32(0.5)))
+    y2 = np.float32(y + y); yy = np.float32(y * y2); wy = np.float32(w * y2)
+    c, s = np.float32(np.float32(1.0) - yy), wy
     R = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], dtype=np.float32)
     S = np.diag(np.array([2.5, 2.5, 2.5, 1], dtype=np.float32))
     T = np.eye(4, dtype=np.float32); T[2, 3] = 0.5
