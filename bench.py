@@ -168,25 +168,25 @@ def main():
                     px += min(8, W - tx * 8) * min(8, H - ty * 8)
                 return px * n_idx, sec
 
-            n, sec = run(16, 1)                                   # calibration: 1/16 of the tiles, one sample index
+            n, sec = run(1, 1)                                    # calibration: the whole frame, one sample index
             rate = n / max(sec, 1e-9)
             want = rate * args.cpu_seconds                        # samples that fit the time budget
-            if want >= W * H:                                     # whole frame, several sample indices
+            if want >= 2 * W * H:                                 # whole frame, several sample indices
                 k, n_idx = 1, int(min(max(want // (W * H), 1), spp_job))
-            else:                                                 # a tile subset of the frame, one sample index
-                k, n_idx = int(max(W * H // max(want, 1), 1)), 1
+            else:                                                 # keep the calibration run as the sample
+                k, n_idx = 1, 1
             n, sec = run(k, n_idx)
             cpu = {"value": round(n / sec / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "port",
                    "sample": f"oracle faithful mode (two-level recursive BVH, non-shrinking t_max, Mat4 inverse per instance per "
                              f"ray, light sampler rebuilt per call), every {k}-th 8x8 tile of the same {W}x{H} frame, sample "
                              f"indices [0,{n_idx}) of the {spp_job}-spp Sobol job: {n} samples in {sec:.1f} s on {cores} threads"}
         out = {
-            "metric": "Msamples/sec (whole node), scene3 MIS/Sobol 1920x1080",
+            "metric": f"Msamples/sec (whole node), scene{args.scene} {args.strategy.upper()}/{args.sampler.capitalize()} {W}x{H}",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"scene{args.scene} {W}x{H} {args.strategy}+{args.sampler}, {spp_job}-spp job, "
-                                   f"{sps} sample indices per step (BASELINE configs[1])",
+                                   f"{sps} sample indices per step" + (" (BASELINE configs[1])" if (args.scene, W, H, spp_job) == (3, 1920, 1080, 1024) else ""),
                        "samples_per_step": samples_per_step, "seconds_to_target_spp": round(W * H * spp_job / (value * 1e6), 3),
                        "parallelism": f"tiles8x8-rr{world}+rccl-film-reduce" if world > 1 else "single-gpu",
                        "bvh": scene_info(prod, scene)},
