@@ -21,6 +21,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--strategy", default="mis")
 ap.add_argument("--sampler", default="sobol")
 ap.add_argument("--tag", default="")
+ap.add_argument("--max-depth", type=int, default=16)
 a = ap.parse_args()
 
 pkg = importlib.import_module("toy-cpu-pathtracing_amd")
@@ -33,7 +34,7 @@ n = a.width * a.height * 3 * 4
 d_acc = C.c_void_p()
 assert hip.hipMalloc(C.byref(d_acc), C.c_size_t(n)) == 0
 hip.hipMemset(d_acc, 0, C.c_size_t(n))
-prm = pkg.make_params(a.spp, a.strategy, a.sampler)
+prm = pkg.make_params(a.spp, a.strategy, a.sampler, max_depth=a.max_depth)
 ms = []
 for i in range(a.reps + 1):
     st = pkg.ffi.Stats()
@@ -41,7 +42,7 @@ for i in range(a.reps + 1):
     ms.append(st.kernel_ms)
 best = min(ms[1:])
 rate = a.width * a.height * a.slice / best / 1e3
-prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=1)
+prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=1, max_depth=a.max_depth)
 st = pkg.ffi.Stats()
 prod.render_accum_device(sc, cam, prm2, 0, 4, d_acc.value, None, stats=st)
 d = st.as_dict()

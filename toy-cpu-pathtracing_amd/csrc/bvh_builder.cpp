@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 
 #include "scene.hpp"
@@ -25,7 +26,9 @@ struct Box {
     }
 };
 
-constexpr float COST_TRAVERSE = 1.0f, COST_TRI = 1.3f;
+// SAH cost ratio and leaf size: defaults measured on MI355X; env overrides exist for sweeps only
+static float COST_TRAVERSE = 1.0f, COST_TRI = 2.0f;   // a watertight triangle test costs about two node steps on gfx950
+static int LEAF_MAX = 2;                             // leaf loops run to the longest leaf of the wave: 2 measured best (+3 %)
 
 struct Builder {
     const std::vector<BuildTri>& tris;
@@ -68,7 +71,7 @@ struct Builder {
                 }
             }
         }
-        if (!force_median && n <= (uint32_t)MAX_LEAF_TRIS && leaf_cost <= best_cost) return make_leaf_here();
+        if (!force_median && n <= (uint32_t)LEAF_MAX && leaf_cost <= best_cost) return make_leaf_here();
         if (force_median || best_axis < 0) {
             // balanced object-median split on the widest axis bounds the remaining depth by log2(n)
             int axis = 0; float ext = -1;
@@ -96,6 +99,8 @@ struct Builder {
 }  // namespace
 
 void build_bvh(const std::vector<BuildTri>& tris, BvhOut* out) {
+    if (const char* e = getenv("MI355PT_BVH_COST_TRI")) COST_TRI = (float)atof(e);
+    if (const char* e = getenv("MI355PT_BVH_LEAF")) LEAF_MAX = std::max(1, std::min(atoi(e), MAX_LEAF_TRIS));
     out->nodes.clear(); out->order.clear();
     Builder b{tris, *out, {}, {}};
     b.idx.resize(tris.size());

@@ -78,8 +78,12 @@ PT_DEV uint32_t perm_packed(uint32_t p) {
     return (uint32_t)(w >> ((p & 7u) * 8u)) & 0xffu;
 }
 
-PT_DEV uint64_t sobol_sample_index(uint32_t morton, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits) {   // :101-156
-    uint64_t sample_index = 0;
+// `hi_digits`/`hi_first`: the digits with index >= hi_first were already permuted and OR-ed into `hi_digits`
+// (tile-uniform part, see sobol_tile_hi_digits); 0 / n_base4_digits computes everything here.
+PT_DEV uint64_t sobol_sample_index(uint32_t morton, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits, uint64_t hi_digits = 0ull,
+                                   uint32_t hi_first = 0xffffu) {   // :101-156
+    uint64_t sample_index = hi_digits;
+    if (hi_first < n_base4_digits) n_base4_digits = hi_first;
     const bool pow2 = (log2_spp & 1u) != 0;
     const int last = pow2 ? 1 : 0;
     const uint64_t dmix = 0x55555555ull * (uint64_t)dimension;
@@ -122,10 +126,46 @@ struct Sampler {
     uint32_t rkey_lo, rkey_hi;   // random-mode stream key
 };
 
+constexpr int SOBOL_HI_DIMS = HASH_TABLE_DIMS;   // every dimension a 16-bounce path can reach has a cached prefix: a wave
+                                                  // must never need the full-length loop for a few deep lanes
 struct SamplerCtx {
     uint32_t mode, seed, log2_spp, n_base4_digits, width;
     const uint64_t* hash_lds;     // murmur(dimension, seed) for dimension < HASH_TABLE_DIMS
+    const uint32_t* hi_lds;       // per-dimension permuted high digits of this wave's 8x8 tile, >> hi_shift (nullptr: none)
+    uint32_t hi_first;            // first digit index covered by hi_lds
+    uint32_t hi_shift;            // bit position of that digit
 };
+// The pixels of an aligned 8x8 tile share every Morton digit above the lowest three, and a digit's permutation
+// only depends on the digits above it and on the dimension (:134-145): for those digits the permuted prefix of the
+// sample index is a function of (tile, dimension) alone.  It is computed once per tile and dimension by one lane.
+PT_DEV uint32_t sobol_hi_first(uint32_t log2_spp) { return (log2_spp + 1u) / 2u + 3u; }
+PT_DEV uint64_t sobol_tile_hi_digits(uint32_t tile_morton_shifted, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits) {
+    const uint32_t first = sobol_hi_first(log2_spp);
+    uint64_t out = 0;
+    const bool pow2 = (log2_spp & 1u) != 0;
+    const uint64_t dmix = 0x55555555ull * (uint64_t)dimension;
+    for (int i = (int)n_base4_digits - 1; i >= (int)first; --i) {
+        int shift = 2 * i - (pow2 ? 1 : 0);
+        uint32_t digit = (uint32_t)((uint64_t)tile_morton_shifted >> shift) & 3u;
+        uint64_t higher = (uint64_t)tile_morton_shifted >> (shift + 2);
+        uint64_t mx = mix_bits(higher ^ dmix) >> 24;
+        uint32_t p = (((uint32_t)(mx >> 32) * 16u) + ((uint32_t)mx % 24u)) % 24u;
+        digit = (perm_packed(p) >> (2u * digit)) & 3u;
+        out |= (uint64_t)digit << shift;
+    }
+#ifdef PT_HI_BREAK
+    out ^= 0x300000000ull;
+#endif
+    return out;
+}
+PT_DEV uint64_t sampler_index(const Sampler& s, const SamplerCtx& c) {
+#ifdef PT_SOBOL_ABLATE   // timing experiment only: skips the digit permutation (wrong sequence)
+    return (uint64_t)s.morton;
+#endif
+    if (c.hi_lds != nullptr && s.dimension < (uint32_t)SOBOL_HI_DIMS)
+        return sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits, (uint64_t)c.hi_lds[s.dimension] << c.hi_shift, c.hi_first);
+    return sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits);
+}
 
 PT_DEV void sampler_start(Sampler& s, const SamplerCtx& c, uint32_t px, uint32_t py, uint32_t sample_index) {   // :198-201
     s.dimension = 0;
@@ -142,13 +182,13 @@ PT_DEV float random_next(Sampler& s) {
     return (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f;
 }
 PT_DEV uint32_t get_1d_bits(Sampler& s, const SamplerCtx& c) {           // :203-213
-    uint64_t si = sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits);
+    uint64_t si = sampler_index(s, c);
     s.dimension += 1;
     uint64_t h = dim_hash(c, s.dimension);
     return fast_owen(sobol_dim0(si), (uint32_t)h);
 }
 PT_DEV void get_2d_bits(Sampler& s, const SamplerCtx& c, uint32_t& b0, uint32_t& b1) {   // :215-230
-    uint64_t si = sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits);
+    uint64_t si = sampler_index(s, c);
     s.dimension += 2;
     uint64_t h = dim_hash(c, s.dimension);
     b0 = fast_owen(sobol_dim0(si), (uint32_t)h);

@@ -89,12 +89,13 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
                                                 PathOut pout) {
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
     __shared__ uint64_t s_hash[HASH_TABLE_DIMS];
+    __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
     __shared__ unsigned s_work;
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < (uint32_t)HASH_TABLE_DIMS; i += 64) s_hash[i] = dim_hash_tab[i];
     __syncthreads();
     uint32_t* stack = s_stack + lane;
-    SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash};
+    SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash, nullptr, 0u, 0u};
     StatCounters st{};
 
     for (;;) {
@@ -104,6 +105,16 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
         __syncthreads();
         if (work >= prm.n_work) break;
         LaneJob job = lane_job<PROBE>(work, lane, cam, prm, probe_xys, n_probe);
+        if (!PROBE && prm.sampler == 1u && sobol_hi_first(prm.log2_spp) < prm.n_base4_digits) {
+            // tile-uniform Sobol digit prefixes: lane d computes dimension d for this tile (lane 0's pixel is the tile origin)
+            uint32_t tile_px = __shfl(job.px, 0), tile_py = __shfl(job.py, 0);
+            sctx.hi_first = sobol_hi_first(prm.log2_spp);
+            sctx.hi_shift = 2u * sctx.hi_first - (prm.log2_spp & 1u);
+            for (uint32_t dmn = lane; dmn < (uint32_t)SOBOL_HI_DIMS; dmn += 64)
+                s_hi[dmn] = (uint32_t)(sobol_tile_hi_digits(encode_morton2_u32(tile_px, tile_py) << prm.log2_spp, dmn, prm.log2_spp, prm.n_base4_digits) >> sctx.hi_shift);
+            sctx.hi_lds = s_hi;
+            __syncthreads();
+        }
         uint32_t s_cur = job.s_cur;
         float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
         Path P{};
@@ -171,12 +182,13 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
                                                 PathOut pout) {
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
     __shared__ uint64_t s_hash[HASH_TABLE_DIMS];
+    __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
     __shared__ unsigned s_work;
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < (uint32_t)HASH_TABLE_DIMS; i += 64) s_hash[i] = dim_hash_tab[i];
     __syncthreads();
     uint32_t* stack = s_stack + lane;
-    SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash};
+    SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash, nullptr, 0u, 0u};
     StatCounters st{};
 
     for (;;) {
@@ -186,6 +198,16 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
         __syncthreads();
         if (work >= prm.n_work) break;
         LaneJob job = lane_job<PROBE>(work, lane, cam, prm, probe_xys, n_probe);
+        if (!PROBE && prm.sampler == 1u && sobol_hi_first(prm.log2_spp) < prm.n_base4_digits) {
+            // tile-uniform Sobol digit prefixes: lane d computes dimension d for this tile (lane 0's pixel is the tile origin)
+            uint32_t tile_px = __shfl(job.px, 0), tile_py = __shfl(job.py, 0);
+            sctx.hi_first = sobol_hi_first(prm.log2_spp);
+            sctx.hi_shift = 2u * sctx.hi_first - (prm.log2_spp & 1u);
+            for (uint32_t dmn = lane; dmn < (uint32_t)SOBOL_HI_DIMS; dmn += 64)
+                s_hi[dmn] = (uint32_t)(sobol_tile_hi_digits(encode_morton2_u32(tile_px, tile_py) << prm.log2_spp, dmn, prm.log2_spp, prm.n_base4_digits) >> sctx.hi_shift);
+            sctx.hi_lds = s_hi;
+            __syncthreads();
+        }
         uint32_t s_cur = job.s_cur;
         float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
         Path P{};
@@ -357,7 +379,7 @@ __global__ void probe_sobol_kernel(uint32_t width, uint32_t seed, uint32_t log2_
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // no LDS hash table here: dim_hash falls back to computing the MurmurHash when the pointer table is absent
-    SamplerCtx c{1u, seed, log2_spp, nb4, width, nullptr};
+    SamplerCtx c{1u, seed, log2_spp, nb4, width, nullptr, nullptr, 0u, 0u};
     Sampler s;
     sampler_start(s, c, xys[3 * i], xys[3 * i + 1], xys[3 * i + 2]);
     uint32_t* o = out + (size_t)i * per;
@@ -451,8 +473,108 @@ hipError_t launch_probe_sobol(uint32_t width, uint32_t seed, uint32_t log2_spp, 
     hipLaunchKernelGGL(probe_sobol_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, width, seed, log2_spp, nb4, d_xys, n, d_pat, n_pat, per, d_out);
     return hipGetLastError();
 }
+int query_resident_waves();
+// ---- experiment: persistent traversal with dynamic ray fetch (Aila & Laine style) --------------------------------
+// Waves loop until a global ray counter is exhausted; a lane whose ray finished takes the next ray at once, so the
+// wave does not idle through the tail of its slowest ray.  Leaves are postponed until enough lanes hold one.
+// Selected with MI355PT_TRAV=2 for probe_intersect only; used to size what a queue-based traversal stage could gain.
+__global__ __launch_bounds__(64) void probe_intersect_dyn_kernel(DevScene sc, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
+                                                                 float* __restrict__ out_t, uint32_t* __restrict__ out_inst,
+                                                                 uint32_t* __restrict__ out_tri, unsigned* __restrict__ counter) {
+    __shared__ uint32_t s_stack[STACK_DEPTH * 64];
+    uint32_t* stack = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    bool have = false, pool_empty = false;
+    uint32_t ray = 0;
+    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+    RaySetup rs{};
+    float t_best = 0.0f;
+    int32_t cur = 0; int sp = 0;
+    Hit hit{}; bool found = false;
+    for (;;) {
+        // ---- refill: every idle lane takes one ray ----
+        unsigned long long idle = __ballot(!have);
+        if (idle != 0ull && !pool_empty) {
+            uint32_t need = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane == (uint32_t)__ffsll((long long)idle) - 1u) base = atomicAdd(counter, need);
+            base = __shfl(base, __ffsll((long long)idle) - 1);
+            if (!have) {
+                uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                uint32_t r = base + rank;
+                if (r < n) {
+                    ray = r; have = true;
+                    ro = mk3(o[3 * r], o[3 * r + 1], o[3 * r + 2]); rd = mk3(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
+                    rs = setup_ray(rd); t_best = 3.402823466e+38f; cur = sc.root; sp = 0; found = false;
+                }
+            }
+            if (base + need >= n) pool_empty = true;
+        }
+        if (__ballot(have) == 0ull) break;
+        // ---- traversal quantum ----
+        for (int q = 0; q < 16; ++q) {
+            bool fin = false;
+            if (have && cur >= 0) {
+                const float4* qn = (const float4*)(sc.nodes + cur);
+                float4 nx = qn[0], ny = qn[1], nz = qn[2];
+                int2 ch = *(const int2*)(qn + 3);
+                float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
+                float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
+                float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
+                float l1y = (ny.y - ro.y) * rs.inv.y, h1y = (ny.w - ro.y) * rs.inv.y;
+                float l0z = (nz.x - ro.z) * rs.inv.z, h0z = (nz.z - ro.z) * rs.inv.z;
+                float l1z = (nz.y - ro.z) * rs.inv.z, h1z = (nz.w - ro.z) * rs.inv.z;
+                float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+                float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_best));
+                float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+                float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_best));
+                bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+                if (hit0 && hit1) { bool first0 = n0 <= n1; stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp; cur = first0 ? ch.x : ch.y; }
+                else if (hit0) cur = ch.x;
+                else if (hit1) cur = ch.y;
+                else if (sp == 0) fin = true;
+                else { --sp; cur = (int32_t)stack[sp * 64]; }
+            }
+            const bool at_leaf = have && !fin && cur < 0;
+            const unsigned long long m_leaf = __ballot(at_leaf), m_node = __ballot(have && !fin && cur >= 0);
+            if (m_leaf != 0ull && (__popcll(m_leaf) >= 16 || m_node == 0ull)) {
+                if (at_leaf) {
+                    uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        TriVerts tv = load_tri(sc.tris, first + i);
+                        float t, b0, b1, b2;
+                        if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
+                            if (!found || t < t_best) { found = true; t_best = t; hit.t = t; hit.tri = first + i; }
+                        }
+                    }
+                    if (sp == 0) fin = true; else { --sp; cur = (int32_t)stack[sp * 64]; }
+                }
+            }
+            if (fin) {
+                const float4* qs = (const float4*)(sc.shade + hit.tri);
+                out_t[ray] = found ? hit.t : -1.0f;
+                out_inst[ray] = found ? __float_as_uint(qs[4].w) : 0xffffffffu;
+                out_tri[ray] = found ? __float_as_uint(qs[5].z) : 0xffffffffu;
+                have = false;
+            }
+            if (__popcll(__ballot(!have)) >= 8 && !pool_empty) break;   // refill
+            if (__ballot(have) == 0ull) break;
+        }
+    }
+}
+
 hipError_t launch_probe_intersect(const DevScene& sc, const float* o, const float* d, uint32_t n, float* t, uint32_t* inst, uint32_t* tri, float* nrm,
                                   hipStream_t stream) {
+    const char* mode = getenv("MI355PT_TRAV");
+    if (mode && mode[0] == '2') {
+        static unsigned* d_ctr = nullptr;
+        if (!d_ctr && hipMalloc((void**)&d_ctr, sizeof(unsigned)) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_ctr, 0, sizeof(unsigned), stream);
+        (void)hipMemsetAsync(nrm, 0, sizeof(float) * 3 * (size_t)n, stream);
+        int grid = std::min<int>((int)((n + 63) / 64), query_resident_waves() * 2);
+        hipLaunchKernelGGL(probe_intersect_dyn_kernel, dim3(grid), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, d_ctr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(probe_intersect_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, nrm);
     return hipGetLastError();
 }
