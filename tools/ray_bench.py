@@ -33,7 +33,3 @@ t2, *_ = sc.probe_intersect(o2, d2)                   # incoherent, same tile or
 perm = rng.permutation(o2.shape[0])
 t3, *_ = sc.probe_intersect(o2[perm], d2[perm])       # incoherent, shuffled across tiles
 print("rays", d.shape[0], o2.shape[0], "hit frac", hit.mean(), (t2 > 0).mean())
-if os.environ.get("MI355PT_TRAV") == "2":
-    os.environ["MI355PT_TRAV"] = "1"
-    ta, ia, tra, _ = sc.probe_intersect(o2[perm], d2[perm])
-    print("dyn vs lockstep identical:", np.array_equal(t3, ta), (t3 == ta).mean())

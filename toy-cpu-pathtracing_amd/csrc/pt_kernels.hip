@@ -7,13 +7,12 @@
 //  * waves are persistent: they pull (tile, sample-chunk) work items from a global counter;
 //  * path state never round-trips through HBM: every lane carries its path in registers and
 //    regenerates the next sample of its pixel when the path ends (in-register compaction);
-//  * inside a wave, lanes are a *pool of small state machines* (pt_kernel, variant 2):
-//      NEW/END -> (film, regenerate) -> TRAV(closest) -> SHADE -> TRAV(shadow) -> TRAV(closest) ...
-//    Closest-hit and any-hit rays share ONE traversal loop.  The wave alternates between traversal
-//    quanta (lanes in TRAV) and batched shading (lanes in SHADE/END/NEW) driven by __ballot/__popcll
-//    votes: a lane that finishes its ray early does not wait for the slowest ray of the wave to finish
-//    before its next ray joins the pool, which is what kept VALU lane utilisation at ~30 % and
-//    load-instruction utilisation at ~15 % in the lock-step variant (profiles/r01_v0_pmc.json);
+//  * inside a wave the path loop is a lock-step state machine: every iteration all 64 lanes trace one closest-hit
+//    ray together, shade together, trace one shadow ray together; a lane whose path ended regenerates the next
+//    sample of its pixel at the top of the next iteration.  Three alternatives were built and measured slower on
+//    MI355X: a lane pool with vote-driven batched shading (516 vs 654 Msamples/s), one merged
+//    shadow+closest traversal loop per iteration (670 vs 851) and persistent traversal with dynamic ray fetch
+//    (1.2-3 vs 5-12 Grays/s in the stand-alone traversal kernel): the simple tight loops win;
 //  * BVH traversal keeps the per-lane stack in LDS (stack[level][lane], conflict-free) and the
 //    MurmurHash(dimension, seed) table of the Sobol sampler in LDS.
 #include <hip/hip_runtime.h>
@@ -29,21 +28,7 @@ namespace pt {
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4   // 128 VGPRs: measured +26 % over the unconstrained 220-VGPR build (latency hiding beats the spills)
 #endif
-#ifndef PT_VARIANT
-#define PT_VARIANT 1     // 1 = lock-step wave (every lane: trace, shade, trace): 654 Msamples/s; 2 = lane pool with shared
-                         // traversal: 516 Msamples/s at best (shading batches run under-filled), kept for A/B runs
-#endif
-#ifndef PT_SHADE_TH
-#define PT_SHADE_TH 24   // batch shading once this many lanes wait (or nothing is traversing)
-#endif
-#ifndef PT_LEAF_TH
-#define PT_LEAF_TH 16    // intersect leaves once this many lanes hold one (or no lane is at an inner node)
-#endif
-#ifndef PT_QUANTUM
-#define PT_QUANTUM 24    // traversal steps between scheduling decisions
-#endif
-
-// work item -> lane assignment shared by both variants
+// work item -> lane assignment
 struct LaneJob { uint32_t px, py, s_cur, s_end; bool valid; };
 template <bool PROBE>
 PT_DEV LaneJob lane_job(uint32_t work, uint32_t lane, const DevCamera& cam, const DevParams& prm, const uint32_t* probe_xys, uint32_t n_probe) {
@@ -78,10 +63,6 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
     atomicAdd(&stats->textured_lookups, (unsigned long long)st.textured_lookups);
 }
 
-#if PT_VARIANT == 1
-// ------------------------------------------------------------------------------------------------------------------
-// Variant 1: lock-step wave.  Every iteration all lanes trace one closest ray, shade, trace one shadow ray.
-// ------------------------------------------------------------------------------------------------------------------
 template <bool STATS, bool PROBE, uint32_t FEAT>
 __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, unsigned* __restrict__ work_counter,
@@ -169,198 +150,6 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
     if (STATS) flush_stats(stats, st);
 }
 
-#else
-// ------------------------------------------------------------------------------------------------------------------
-// Variant 2: lane pool.  Stages per lane; closest and shadow rays share one traversal loop.
-// ------------------------------------------------------------------------------------------------------------------
-enum : uint32_t { LS_NEW = 0, LS_END = 1, LS_SHADE = 2, LS_TRAV = 3, LS_DONE = 4 };
-
-template <bool STATS, bool PROBE, uint32_t FEAT>
-__global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
-                                                float* __restrict__ accum, unsigned* __restrict__ work_counter,
-                                                DevStats* __restrict__ stats, const uint32_t* __restrict__ probe_xys, uint32_t n_probe,
-                                                PathOut pout) {
-    __shared__ uint32_t s_stack[STACK_DEPTH * 64];
-    __shared__ uint64_t s_hash[HASH_TABLE_DIMS];
-    __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
-    __shared__ unsigned s_work;
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t i = lane; i < (uint32_t)HASH_TABLE_DIMS; i += 64) s_hash[i] = dim_hash_tab[i];
-    __syncthreads();
-    uint32_t* stack = s_stack + lane;
-    SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash, nullptr, 0u, 0u};
-    StatCounters st{};
-
-    for (;;) {
-        if (lane == 0) s_work = atomicAdd(work_counter, 1u);
-        __syncthreads();
-        const uint32_t work = s_work;
-        __syncthreads();
-        if (work >= prm.n_work) break;
-        LaneJob job = lane_job<PROBE>(work, lane, cam, prm, probe_xys, n_probe);
-        if (!PROBE && prm.sampler == 1u && sobol_hi_first(prm.log2_spp) < prm.n_base4_digits) {
-            // tile-uniform Sobol digit prefixes: lane d computes dimension d for this tile (lane 0's pixel is the tile origin)
-            uint32_t tile_px = __shfl(job.px, 0), tile_py = __shfl(job.py, 0);
-            sctx.hi_first = sobol_hi_first(prm.log2_spp);
-            sctx.hi_shift = 2u * sctx.hi_first - (prm.log2_spp & 1u);
-            for (uint32_t dmn = lane; dmn < (uint32_t)SOBOL_HI_DIMS; dmn += 64)
-                s_hi[dmn] = (uint32_t)(sobol_tile_hi_digits(encode_morton2_u32(tile_px, tile_py) << prm.log2_spp, dmn, prm.log2_spp, prm.n_base4_digits) >> sctx.hi_shift);
-            sctx.hi_lds = s_hi;
-            __syncthreads();
-        }
-        uint32_t s_cur = job.s_cur;
-        float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
-        Path P{};
-        uint32_t stage = (job.valid && s_cur < job.s_end) ? LS_NEW : LS_DONE;
-
-        // traversal state of this lane's current ray
-        f3 t_ro = mk3(0, 0, 0), t_rd = mk3(0, 0, 1);
-        RaySetup rs{};
-        float t_best = 0.0f;
-        int32_t cur = 0;
-        int sp = 0;
-        Hit hit{};
-        bool found = false, t_shadow = false, t_fin = false;
-        // what follows a shadow ray: the light contribution, and the next closest ray (P.ro/P.rd) unless the path ended
-        float sh_c[4] = {0, 0, 0, 0};
-        bool end_after_shadow = false;
-
-        unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        unsigned long long t_loop0 = 0;
-        if (STATS) t_loop0 = __builtin_amdgcn_s_memtime();
-
-        for (;;) {
-            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsa = 0, tsb = 0;
-            if (STATS) ts0 = __builtin_amdgcn_s_memtime();
-            // ---- (1) rays that finished: shadow -> apply + continue with the pending ray; closest -> SHADE ----
-            if (stage == LS_TRAV && t_fin) {
-                if (t_shadow) {
-                    if (!found) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh_c[i];
-                    }
-                    if (end_after_shadow) stage = LS_END;
-                    else {
-                        t_ro = P.ro; t_rd = P.rd; rs = setup_ray(t_rd); t_best = 3.402823466e+38f;
-                        cur = sc.root; sp = 0; found = false; t_shadow = false; t_fin = false;
-                        if (STATS) st.closest_rays++;
-                    }
-                } else {
-                    stage = LS_SHADE;
-                    if (STATS && found) st.closest_hits++;
-                }
-            }
-            // ---- (2) batched film / regenerate / shade ----
-            const unsigned long long m_wait = __ballot(stage == LS_NEW || stage == LS_END || stage == LS_SHADE);
-            const unsigned long long m_trav = __ballot(stage == LS_TRAV);
-            if (m_wait == 0ull && m_trav == 0ull) break;                       // every lane is DONE
-            if (m_wait != 0ull && (__popcll(m_wait) >= PT_SHADE_TH || m_trav == 0ull)) {
-                if (stage == LS_END) {
-                    film_add<PROBE>(P, sc, prm, acc_r, acc_g, acc_b, pout, work * 64 + lane);
-                    s_cur += 1;
-                    stage = s_cur < job.s_end ? LS_NEW : LS_DONE;
-                }
-                if (STATS) ts1 = __builtin_amdgcn_s_memtime();
-                bool start_closest = false;
-                if (stage == LS_NEW) { regen_path<STATS>(P, sctx, cam, job.px, job.py, s_cur, st); start_closest = true; }
-                else if (stage == LS_SHADE) {
-                    ShadowReq sh{};
-                    bool end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, found, hit, sh, st, tsa, tsb);
-                    if (sh.on) {
-                        t_ro = sh.o; t_rd = sh.d; rs = setup_ray(t_rd); t_best = sh.t;
-                        cur = sc.root; sp = 0; found = false; t_shadow = true; t_fin = false;
-                        end_after_shadow = end_path;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sh_c[i] = sh.c[i];
-                        stage = LS_TRAV;
-                        if (STATS) st.shadow_rays++;
-                    } else if (end_path) stage = LS_END;
-                    else start_closest = true;
-                }
-                if (start_closest) {
-                    t_ro = P.ro; t_rd = P.rd; rs = setup_ray(t_rd); t_best = 3.402823466e+38f;
-                    cur = sc.root; sp = 0; found = false; t_shadow = false; t_fin = false;
-                    stage = LS_TRAV;
-                    if (STATS) st.closest_rays++;
-                }
-                if (STATS) {
-                    ts2 = __builtin_amdgcn_s_memtime();
-                    tp[4] += ts1 - ts0; tp[2] += ts2 - ts1;
-                }
-                continue;   // re-vote: lanes that just ended may be filmed/regenerated before the next quantum
-            }
-            // ---- (3) traversal quantum over the pool ----
-            if (STATS) ts1 = __builtin_amdgcn_s_memtime();
-            for (int q = 0; q < PT_QUANTUM; ++q) {
-                const bool trav = stage == LS_TRAV && !t_fin;
-                const bool at_node = trav && cur >= 0;
-                if (at_node) {
-                    const float4* qn = (const float4*)(sc.nodes + cur);
-                    float4 nx = qn[0], ny = qn[1], nz = qn[2];
-                    int2 ch = *(const int2*)(qn + 3);
-                    if (STATS) { if (t_shadow) st.nodes_shadow++; else st.nodes_closest++; }
-                    float l0x = (nx.x - t_ro.x) * rs.inv.x, h0x = (nx.z - t_ro.x) * rs.inv.x;
-                    float l1x = (nx.y - t_ro.x) * rs.inv.x, h1x = (nx.w - t_ro.x) * rs.inv.x;
-                    float l0y = (ny.x - t_ro.y) * rs.inv.y, h0y = (ny.z - t_ro.y) * rs.inv.y;
-                    float l1y = (ny.y - t_ro.y) * rs.inv.y, h1y = (ny.w - t_ro.y) * rs.inv.y;
-                    float l0z = (nz.x - t_ro.z) * rs.inv.z, h0z = (nz.z - t_ro.z) * rs.inv.z;
-                    float l1z = (nz.y - t_ro.z) * rs.inv.z, h1z = (nz.w - t_ro.z) * rs.inv.z;
-                    float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
-                    float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_best));
-                    float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
-                    float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_best));
-                    bool hit0 = n0 <= f0, hit1 = n1 <= f1;
-                    if (hit0 && hit1) {
-                        bool first0 = n0 <= n1;
-                        stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp;
-                        cur = first0 ? ch.x : ch.y;
-                    } else if (hit0) cur = ch.x;
-                    else if (hit1) cur = ch.y;
-                    else if (sp == 0) t_fin = true;
-                    else { --sp; cur = (int32_t)stack[sp * 64]; }
-                }
-                // leaves are postponed until enough lanes hold one, so the triangle test runs on a well-filled wave
-                const bool at_leaf = stage == LS_TRAV && !t_fin && cur < 0;
-                const unsigned long long m_leaf = __ballot(at_leaf);
-                const unsigned long long m_node = __ballot(stage == LS_TRAV && !t_fin && cur >= 0);
-                if (m_leaf != 0ull && (__popcll(m_leaf) >= PT_LEAF_TH || m_node == 0ull)) {
-                    if (at_leaf) {
-                        uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
-                        for (uint32_t i = 0; i < cnt; ++i) {
-                            TriVerts tv = load_tri(sc.tris, first + i);
-                            float t, b0, b1, b2;
-                            if (STATS) { if (t_shadow) st.tris_shadow++; else st.tris_closest++; }
-                            if (intersect_triangle(t_ro, t_rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
-                                if (t_shadow) { found = true; break; }
-                                if (!found || t < t_best) { found = true; t_best = t; hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = first + i; }
-                            }
-                        }
-                        if (t_shadow && found) t_fin = true;                 // any hit ends a shadow ray
-                        else if (sp == 0) t_fin = true;
-                        else { --sp; cur = (int32_t)stack[sp * 64]; }
-                    }
-                }
-                // leave the quantum when the pool has drained enough to make a scheduling decision worthwhile
-                const unsigned long long m_live = __ballot(stage == LS_TRAV && !t_fin);
-                if (m_live == 0ull) break;
-                if (__popcll(__ballot(stage == LS_TRAV && t_fin)) + __popcll(m_wait) >= PT_SHADE_TH) break;
-            }
-            if (STATS) { ts2 = __builtin_amdgcn_s_memtime(); tp[1] += ts2 - ts1; tp[0] += ts1 - ts0; }
-        }
-
-        if (STATS && lane == 0) {
-            tp[5] = __builtin_amdgcn_s_memtime() - t_loop0;
-            for (int i = 0; i < 10; ++i) atomicAdd(&stats->phase_cycles[i], tp[i]);
-        }
-        if (!PROBE && job.valid) {
-            size_t o = ((size_t)job.py * cam.width + job.px) * 3;
-            if (prm.chunks == 1) { accum[o] += acc_r; accum[o + 1] += acc_g; accum[o + 2] += acc_b; }
-            else { atomicAdd(accum + o, acc_r); atomicAdd(accum + o + 1, acc_g); atomicAdd(accum + o + 2, acc_b); }
-        }
-    }
-    if (STATS) flush_stats(stats, st);
-}
-#endif
 
 // Sensor::to_rgb (sensor.rs:81-88) + ReinhardToneMap (tone_map.rs:20-28) + sRGB OETF (eotf.rs:54-61)
 __global__ void resolve_kernel(const float* __restrict__ accum, uint32_t n_values, float inv_unused, uint32_t spp, float* __restrict__ out) {
@@ -473,108 +262,8 @@ hipError_t launch_probe_sobol(uint32_t width, uint32_t seed, uint32_t log2_spp, 
     hipLaunchKernelGGL(probe_sobol_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, width, seed, log2_spp, nb4, d_xys, n, d_pat, n_pat, per, d_out);
     return hipGetLastError();
 }
-int query_resident_waves();
-// ---- experiment: persistent traversal with dynamic ray fetch (Aila & Laine style) --------------------------------
-// Waves loop until a global ray counter is exhausted; a lane whose ray finished takes the next ray at once, so the
-// wave does not idle through the tail of its slowest ray.  Leaves are postponed until enough lanes hold one.
-// Selected with MI355PT_TRAV=2 for probe_intersect only; used to size what a queue-based traversal stage could gain.
-__global__ __launch_bounds__(64) void probe_intersect_dyn_kernel(DevScene sc, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
-                                                                 float* __restrict__ out_t, uint32_t* __restrict__ out_inst,
-                                                                 uint32_t* __restrict__ out_tri, unsigned* __restrict__ counter) {
-    __shared__ uint32_t s_stack[STACK_DEPTH * 64];
-    uint32_t* stack = s_stack + threadIdx.x;
-    const uint32_t lane = threadIdx.x;
-    bool have = false, pool_empty = false;
-    uint32_t ray = 0;
-    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
-    RaySetup rs{};
-    float t_best = 0.0f;
-    int32_t cur = 0; int sp = 0;
-    Hit hit{}; bool found = false;
-    for (;;) {
-        // ---- refill: every idle lane takes one ray ----
-        unsigned long long idle = __ballot(!have);
-        if (idle != 0ull && !pool_empty) {
-            uint32_t need = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (lane == (uint32_t)__ffsll((long long)idle) - 1u) base = atomicAdd(counter, need);
-            base = __shfl(base, __ffsll((long long)idle) - 1);
-            if (!have) {
-                uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                uint32_t r = base + rank;
-                if (r < n) {
-                    ray = r; have = true;
-                    ro = mk3(o[3 * r], o[3 * r + 1], o[3 * r + 2]); rd = mk3(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
-                    rs = setup_ray(rd); t_best = 3.402823466e+38f; cur = sc.root; sp = 0; found = false;
-                }
-            }
-            if (base + need >= n) pool_empty = true;
-        }
-        if (__ballot(have) == 0ull) break;
-        // ---- traversal quantum ----
-        for (int q = 0; q < 16; ++q) {
-            bool fin = false;
-            if (have && cur >= 0) {
-                const float4* qn = (const float4*)(sc.nodes + cur);
-                float4 nx = qn[0], ny = qn[1], nz = qn[2];
-                int2 ch = *(const int2*)(qn + 3);
-                float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
-                float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
-                float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
-                float l1y = (ny.y - ro.y) * rs.inv.y, h1y = (ny.w - ro.y) * rs.inv.y;
-                float l0z = (nz.x - ro.z) * rs.inv.z, h0z = (nz.z - ro.z) * rs.inv.z;
-                float l1z = (nz.y - ro.z) * rs.inv.z, h1z = (nz.w - ro.z) * rs.inv.z;
-                float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
-                float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_best));
-                float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
-                float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_best));
-                bool hit0 = n0 <= f0, hit1 = n1 <= f1;
-                if (hit0 && hit1) { bool first0 = n0 <= n1; stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp; cur = first0 ? ch.x : ch.y; }
-                else if (hit0) cur = ch.x;
-                else if (hit1) cur = ch.y;
-                else if (sp == 0) fin = true;
-                else { --sp; cur = (int32_t)stack[sp * 64]; }
-            }
-            const bool at_leaf = have && !fin && cur < 0;
-            const unsigned long long m_leaf = __ballot(at_leaf), m_node = __ballot(have && !fin && cur >= 0);
-            if (m_leaf != 0ull && (__popcll(m_leaf) >= 16 || m_node == 0ull)) {
-                if (at_leaf) {
-                    uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
-                    for (uint32_t i = 0; i < cnt; ++i) {
-                        TriVerts tv = load_tri(sc.tris, first + i);
-                        float t, b0, b1, b2;
-                        if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
-                            if (!found || t < t_best) { found = true; t_best = t; hit.t = t; hit.tri = first + i; }
-                        }
-                    }
-                    if (sp == 0) fin = true; else { --sp; cur = (int32_t)stack[sp * 64]; }
-                }
-            }
-            if (fin) {
-                const float4* qs = (const float4*)(sc.shade + hit.tri);
-                out_t[ray] = found ? hit.t : -1.0f;
-                out_inst[ray] = found ? __float_as_uint(qs[4].w) : 0xffffffffu;
-                out_tri[ray] = found ? __float_as_uint(qs[5].z) : 0xffffffffu;
-                have = false;
-            }
-            if (__popcll(__ballot(!have)) >= 8 && !pool_empty) break;   // refill
-            if (__ballot(have) == 0ull) break;
-        }
-    }
-}
-
 hipError_t launch_probe_intersect(const DevScene& sc, const float* o, const float* d, uint32_t n, float* t, uint32_t* inst, uint32_t* tri, float* nrm,
                                   hipStream_t stream) {
-    const char* mode = getenv("MI355PT_TRAV");
-    if (mode && mode[0] == '2') {
-        static unsigned* d_ctr = nullptr;
-        if (!d_ctr && hipMalloc((void**)&d_ctr, sizeof(unsigned)) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemsetAsync(d_ctr, 0, sizeof(unsigned), stream);
-        (void)hipMemsetAsync(nrm, 0, sizeof(float) * 3 * (size_t)n, stream);
-        int grid = std::min<int>((int)((n + 63) / 64), query_resident_waves() * 2);
-        hipLaunchKernelGGL(probe_intersect_dyn_kernel, dim3(grid), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, d_ctr);
-        return hipGetLastError();
-    }
     hipLaunchKernelGGL(probe_intersect_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, nrm);
     return hipGetLastError();
 }
