@@ -141,9 +141,10 @@ def test_gpu_pt_nee_mis_consistency(product, pkg):
     assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
 
 
-@pytest.mark.parametrize("scene_id,strategy", [(8, "mis"), (10, "mis"), (0, "nee"), (17, "nee"), (17, "mis")])
+@pytest.mark.parametrize("scene_id,strategy", [(8, "mis"), (10, "mis"), (0, "nee"), (17, "nee"), (17, "mis"), (11, "mis"), (11, "nee")])
 def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
-    """Glass (scene 8: dispersive, wavelength termination), thin plastic (scene 10), plain Lambert (scene 0)."""
+    """Glass (scene 8: dispersive, wavelength termination), thin plastic (scene 10), plain Lambert (scene 0), rough clearcoat
+    over rough metal (scene 17), rough SF11 glass (scene 11: microfacet reflection/transmission + light connection)."""
     pair = {}
     for name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()
@@ -160,13 +161,25 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     assert same_term.mean() >= 0.995
     close = np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)
     assert close.mean() >= 0.98, close.mean()
-    assert abs(Lg[:, 0].mean() - Lc[:, 0].mean()) <= 0.02 * Lc[:, 0].mean()
+    # The reference accumulates NaN samples without complaint (sensor.rs:42 only logs).  Rough SF11 glass under MIS makes
+    # some: below 370 nm the eta LUT is 0 -> eta' = 1 (dielectric.rs:144-148), the "refracted" ray is -wo, and whenever
+    # dot(wi,wm) + dot(wo,wm) rounds to exactly 0 the sample has f = 0 (spectrum / 0 -> 0), pdf = inf and the MIS weight
+    # inf/(inf+0) = NaN.  Whether the sum rounds to 0 depends on the last ulp of sin/cos in the GGX normal sample, so
+    # the two sides agree on the mechanism and the rate, not on every sample: both must be rare, of similar count, and
+    # only ever on hero wavelengths below 370 nm.
+    nan_g, nan_c = np.isnan(Lg).any(axis=1), np.isnan(Lc).any(axis=1)
+    bad = nan_g | nan_c
+    assert bad.mean() <= 5e-3, bad.mean()
+    if nan_c.sum() >= 20:
+        assert 0.5 * nan_c.sum() <= nan_g.sum() <= 2.0 * nan_c.sum(), (nan_g.sum(), nan_c.sum())
+    assert np.all(lg[nan_g, 0] < 370.0) and np.all(lc[nan_c, 0] < 370.0)
+    assert abs(Lg[~bad, 0].mean() - Lc[~bad, 0].mean()) <= 0.02 * Lc[~bad, 0].mean()
     # the render path uses a kernel specialised for the scene's materials (probes use the all-features build):
     # compare a small image too (reference metric, regression_test.rs:6-40)
     prm8 = pkg.make_params(8, strategy, "sobol")
     qg = product.quantize_u8(product.render(pair["gpu"][0], pair["gpu"][1], prm8))
     qc = oracle.quantize_u8(oracle.render(pair["cpu"][0], pair["cpu"][1], prm8))
-    assert linear_rmse_u8(qg, qc) <= 0.01
+    assert linear_rmse_u8(qg, qc) <= (0.01 if scene_id != 11 else 0.03)    # a NaN sample blacks out its pixel (`as u8`)
 
 
 def test_shards_tile_the_frame(product, pkg):

@@ -240,7 +240,6 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
         case MI355PT_MAT_PLASTIC:
             if ((rc = im.lower_spectrum(d->eta, &m.eta, false, &err))) return fail(rc, "eta: " + err);
             if ((rc = im.lower_spectrum(d->color, &m.color, d->type == MI355PT_MAT_PLASTIC, &err))) return fail(rc, err);
-            if (d->roughness >= 1e-3f) return fail(MI355PT_E_INVALID, "rough dielectrics are not implemented on the device yet (roughness must be < 1e-3)");
             break;
         case MI355PT_MAT_CLEARCOAT:
             if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, err);

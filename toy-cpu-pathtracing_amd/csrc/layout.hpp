@@ -151,7 +151,7 @@ struct DevParams {
 
 // Scene feature bits: the host picks the smallest kernel specialisation that covers the scene's materials, so a
 // Lambert-only Cornell box does not carry the registers and code of the clearcoat / dielectric / texture paths.
-enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ALL = 15 };
+enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_ALL = 31 };
 
 struct DevStats {
     unsigned long long samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;

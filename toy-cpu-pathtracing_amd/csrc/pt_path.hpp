@@ -226,6 +226,14 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
 #pragma unroll
                     for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * ((pf[i] * Le[i]) * tf)) * w;
                 }
+            } else if (prm.strategy != 1u || prev_spec) {
+                // The reference adds T * (f * 0 / pdf) * w even when the next vertex is not a light
+                // (pt_renderer.rs:43, mis_renderer.rs:163-180 with pdf_light = 0).  That is +0 unless the sample's
+                // pdf or throughput is inf/NaN (rough transmission at grazing half vectors), in which case it poisons
+                // the sample with NaN exactly like the CPU path; keep that behaviour bit for bit.
+                float w = (prm.strategy == 2u && !prev_spec) ? balance_heuristic(p_pdf, 0.0f) : 1.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * ((pf[i] * 0.0f) * tf)) * w;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) T[i] = T[i] * (pf[i] * tf);
@@ -258,10 +266,11 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
             const bool is_diel = (FEAT & FEAT_DIEL) && (mtype == MT_GLASS || mtype == MT_PLASTIC);
             float uc = 0.0f;
             f2 uv = f2{0.0f, 0.0f};
+            const bool rough_diel = (FEAT & FEAT_ROUGH) && is_diel && mat->roughness >= 1e-3f;    // !effectively_smooth (dielectric.rs:25-27)
             if (is_diel) {
                 uc = get_1d(smp, sctx);
                 // Plastic indexes a *textured* colour with the random uv (plastic_material.rs:123-126, Q15)
-                if (mtype == MT_PLASTIC && mat->color.kind == SPK_TEXTURE) uv = get_2d(smp, sctx); else smp.dimension += 2;
+                if (rough_diel || (mtype == MT_PLASTIC && mat->color.kind == SPK_TEXTURE)) uv = get_2d(smp, sctx); else smp.dimension += 2;
             }
             else if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) { uc = get_1d(smp, sctx); uv = get_2d(smp, sctx); }
             else { smp.dimension += 1; uv = get_2d(smp, sctx); }
@@ -286,7 +295,9 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
             float geo_wo = dot(ng_t, wo);
 
             // state the light connection needs to evaluate the BSDF again (BsdfSurfaceMaterial::{evaluate,pdf})
-            uint32_t nee_kind = 0;            // 0 none, 1 Lambert, 2 clearcoat
+            uint32_t nee_kind = 0;            // 0 none, 1 Lambert, 2 clearcoat, 3 rough dielectric
+            float d_er[4] = {1, 1, 1, 1};     // rough dielectric: relative eta per wavelength, flags
+            bool d_thin = false, d_plastic = false;
             float albedo[4] = {0, 0, 0, 0};   // Lambert albedo / clearcoat base colour
             float cc_tint[4] = {1, 1, 1, 1};
             float cc_fc = 0.0f, cc_alpha_c = 0.0f, cc_alpha_b = 0.0f, cc_r0c = 0.0f, cc_r0d = 0.0f;
@@ -319,6 +330,65 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 if (eta[0] == 0.0f) { eta[0] = eta[1] = eta[2] = eta[3] = 1.0f; eta_const = true; }   // DielectricBsdf::new :144-148
                 bool entering = geo_wo > 0.0f;
                 bool thin = mat->thin != 0;
+                if (rough_diel) {
+                    // DielectricBsdf::sample_microfacet (dielectric.rs:217-365), alpha = roughness (glass_material.rs:120-126)
+                    nee_kind = 3; d_thin = thin; d_plastic = mtype == MT_PLASTIC;
+                    const float alpha = mat->roughness;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d_er[i] = (thin || entering) ? eta[i] : sdiv(1.0f, eta[i]);
+                    if (wo_nm.z != 0.0f) {
+                        f3 wm = ggx_sample_wm(alpha, alpha, wo_nm, uv);
+                        float wodm = dot(wo_nm, wm);
+                        float fr4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fr4[i] = fresnel_dielectric1(fabsf(wodm), d_er[i]);
+                        float favg = (((0.0f + fr4[0]) + fr4[1]) + fr4[2] + fr4[3]) / 4.0f;
+                        float pr = favg, pt = 1.0f - favg;
+                        if (thin) { float r = favg, t = 1.0f - r, r2 = r * r; pr = r2 > 1.0f ? 1.0f : r + (t * t * r) / (1.0f - r2); pt = t; }
+                        f3 wi = mk3(0, 0, 1);
+                        if (uc < pr / (pr + pt)) {                                // sample_microfacet_reflection :284-314
+                            f3 w = wm * (2.0f * wodm) - wo_nm;
+                            float cd = fabsf(wodm);
+                            if (wo_nm.z * w.z > 0.0f && !(cd < 1e-6f)) {
+                                sampled = true; wi = w;
+                                s_pdf = ggx_Dw(alpha, alpha, wo_nm, wm) / (4.0f * cd) * (pr / (pr + pt));
+                                float dg = ggx_D(alpha, alpha, wm) * ggx_G(alpha, alpha, wo_nm, w);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) s_f[i] = fr4[i] * dg * fabsf(w.z) / (4.0f * fabsf(wo_nm.z));   // extra |cos wi| (Q8)
+                            }
+                        } else if (thin) {                                        // sample_specular_transmission_thin_surface :346-365
+                            sampled = true; wi = mk3(-wo_nm.x, -wo_nm.y, -wo_nm.z); s_pdf = pt / (pr + pt);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_f[i] = 1.0f - fr4[i];
+                        } else {                                                  // sample_microfacet_transmission :316-344
+                            if (!eta_const) wl.term = true;
+                            const float etap = d_er[0];
+                            f3 wmr = entering ? wm : -wm;
+                            f3 w;
+                            if (refract(wo_nm, wmr, etap, w) && !(wo_nm.z * w.z > 0.0f) && fabsf(w.z) != 0.0f) {
+                                float sden = dot(w, wm) + wodm / etap;
+                                float denom = sden * sden;
+                                float dwm = fabsf(dot(w, wm)) / denom;
+                                sampled = true; wi = w;
+                                s_pdf = ggx_Dw(alpha, alpha, wo_nm, wm) * dwm * (pt / (pr + pt));
+                                float dg = ggx_D(alpha, alpha, wm) * ggx_G(alpha, alpha, wo_nm, w);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    s_f[i] = sdiv((1.0f - fr4[i]) * dg * fabsf(dot(w, wm)) * fabsf(wodm), denom * fabsf(wo_nm.z) * etap * etap);   // spectrum / f32: x/0 -> 0
+                            }
+                        }
+                        if (sampled) {
+                            if (d_plastic && dot(wi, wo_nm) < 0.0f) {
+                                float col[4];
+                                DevSpectrum cs = load_spectrum(&mat->color);
+                                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, uv, col, st);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) s_f[i] = s_f[i] * col[i];
+                            }
+                            wi_sh = to_world(nf, wi);
+                        }
+                    }
+                } else
                 if (wo_nm.z != 0.0f) {
                     float er[4], fr4[4], favg;
 #pragma unroll
@@ -532,7 +602,46 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     f3 wi_nm = to_local(nf, wi_t);
                     float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
                     float gwi = dot(ng_t, wi_t);
-                    if (!(FEAT & FEAT_CC) || nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
+                    if ((FEAT & FEAT_ROUGH) && nee_kind == 3u) {                 // DielectricBsdf::{evaluate_microfacet,pdf_microfacet} (:468-645)
+                        const float alpha = mat->roughness;
+                        const float es = d_er[0];
+                        float co = wo_nm.z, ci = wi_nm.z;
+                        bool refl = ci * co > 0.0f;
+                        float etap = !refl ? (co > 0.0f ? es : 1.0f / es) : 1.0f;
+                        f3 wm = wi_nm * etap + wo_nm;
+                        bool ok = !(ci == 0.0f || co == 0.0f || dot(wm, wm) == 0.0f);
+                        if (ok) {
+                            wm = normalize(wm);
+                            if (wm.z < 0.0f) wm = -wm;
+                            if (dot(wm, wi_nm) * ci < 0.0f || dot(wm, wo_nm) * co < 0.0f) ok = false;
+                        }
+                        if (ok) {
+                            float wodm = dot(wo_nm, wm), widm = dot(wi_nm, wm);
+                            float fr4[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) fr4[i] = fresnel_dielectric1(fabsf(wodm), d_er[i]);
+                            float pr = (((0.0f + fr4[0]) + fr4[1]) + fr4[2] + fr4[3]) / 4.0f, pt = 1.0f - pr;
+                            float dg = ggx_D(alpha, alpha, wm) * ggx_G(alpha, alpha, wo_nm, wi_nm);
+                            if (refl) {
+                                pdf_b = ggx_Dw(alpha, alpha, wo_nm, wm) / (4.0f * fabsf(wodm)) * pr / (pr + pt);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) fl[i] = fr4[i] * dg / (4.0f * fabsf(wo_nm.z));
+                            } else {
+                                float sden = widm + wodm / es;
+                                float denom = sden * sden;
+                                pdf_b = d_thin ? pt / (pr + pt) : ggx_Dw(alpha, alpha, wo_nm, wm) * (fabsf(widm) / denom) * pt / (pr + pt);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) fl[i] = sdiv((1.0f - fr4[i]) * dg * fabsf(widm) * fabsf(wodm), denom * fabsf(wo_nm.z) * es * es);
+                            }
+                        }
+                        if (d_plastic && dot(wi_nm, wo_nm) < 0.0f) {              // plastic_material.rs:169-172 (surface uv here)
+                            float col[4];
+                            DevSpectrum cs = load_spectrum(&mat->color);
+                            eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, col, st);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) fl[i] = fl[i] * col[i];
+                        }
+                    } else if (!(FEAT & FEAT_CC) || nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
                         if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
                             pdf_b = fabsf(wi_nm.z) / PI_F;
 #pragma unroll

@@ -265,7 +265,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     features = lights.size() == 1 ? 0u : FEAT_MLIGHT;
     for (const HostInstance& inst : instances) {
         const DevMaterial& m = materials[inst.mat];
-        if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL;
+        if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | (m.roughness >= 1e-3f ? FEAT_ROUGH : 0u);
         if (m.type == MT_CLEARCOAT) features |= FEAT_CC;
         if (m.normal_tex != 0xffffffffu || m.color.kind == SPK_TEXTURE || m.cc_tint.kind == SPK_TEXTURE) features |= FEAT_TEX;
     }

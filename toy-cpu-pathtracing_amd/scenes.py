@@ -111,10 +111,10 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
         _room(scene, p)
         cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
-    elif scene_id == 8:    # scene_8.rs:17-27: SF11 glass hero
+    elif scene_id in (8, 11):    # scene_8.rs:17-27: SF11 glass hero; scene_11.rs:15-26: the same with roughness 0.2
         g = scene.add_mesh(_asset("bunny"))
         d = MaterialDesc(); d.type = MAT_GLASS; d.eta = Spectrum.lut(scene.add_lut470(p["glass_sf11_eta"]))
-        d.normal_tex = NONE; d.thin = 0; d.roughness = 0.0; d.color = Spectrum.constant(1.0)
+        d.normal_tex = NONE; d.thin = 0; d.roughness = 0.0 if scene_id == 8 else 0.2; d.color = Spectrum.constant(1.0)
         scene.add_instance(g, scene.add_material(d))
         _room(scene, p)
         cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
