@@ -8,8 +8,9 @@ are per (pixel, sample), so 16 steps of 64 compose exactly the 1024-spp image). 
 LUTs, tables, textures) are resident in HBM before the timed region; the film accumulators stay in HBM.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's 8x8 pixel tiles are dealt round-robin to
-the ranks (scene replicated), each step every rank renders its tiles and the linear film is summed onto rank 0 with
-one RCCL reduce over xGMI (strong scaling: the frame is fixed).
+the ranks (scene replicated); every step each rank renders its own tiles into its own linear film, with no data-path
+collective, and after the K-th step the films are summed onto rank 0 with ONE RCCL reduce over xGMI, inside the timed
+region (strong scaling: the frame is fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -88,14 +89,12 @@ def main():
         return render_accum
 
     def step(i, events=None):
-        # this rank's tiles for the step's sample indices, then ONE RCCL film reduce over xGMI (linear, pre-tonemap)
+        # this rank's tiles for the step's sample indices, added into the rank-local linear film (no collective)
         if events:
             events[0].record()
         mg.render_frame_sharded(render_slice(i % n_slices), accum, rank, world, reduce=False)
         if events:
             events[1].record()       # brackets exactly the path-tracing launch on the stream it was launched on
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
 
     def barrier():
         if world > 1:
@@ -110,6 +109,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, ev[i])
+    mg.reduce_film(accum, world)     # the job's single film reduce (linear sums, pre-tonemap), timed
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
@@ -133,7 +133,7 @@ def main():
         achieved = bps * launch_samples / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,
-                    "kernel": "pt_kernel<false,false>", "kernel_ms_avg": round(avg_ms, 3),
+                    "kernel": "pt_kernel<STATS=false,PROBE=false,FEAT=scene feature mask>", "kernel_ms_avg": round(avg_ms, 3),
                     "algorithmic_bytes_per_sample": round(bps, 1),
                     "per_sample": {k: round(sd[k] / max(sd["samples"], 1), 3) for k in
                                    ("closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow",
@@ -141,7 +141,15 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh: separate
+                # FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied); only valid for
+                # the workload it was collected on
+                pj = json.load(open(pmc))
+                wl = {"scene": args.scene, "width": W, "height": H, "spp": spp_job, "spp_per_step": sps,
+                      "strategy": args.strategy, "sampler": args.sampler, "n_gpus": world}
+                if pj.get("workload") == wl:
+                    roofline["traffic"] = pj.get("hbm_bytes_per_launch")
+                    roofline["algorithmic_bytes_per_launch"] = round(bps * launch_samples)
             except Exception:
                 pass
         # ---- CPU baseline: the oracle in faithful mode on this box's host cores (rank 0, N=1 only) ----
@@ -202,7 +210,7 @@ def main():
 
 
 def scene_info(prod, scene):
-    return "flat BVH2, 64B nodes, <=4 tris/leaf"
+    return "flat single-level BVH2 (sweep SAH), 64 B nodes with both child boxes, <=2 tris/leaf"
 
 
 if __name__ == "__main__":

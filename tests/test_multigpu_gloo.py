@@ -25,18 +25,28 @@ def _worker(rank, world, port, out_path):
     orc.set_faithful(sc, False)
     W, H, spp = 40, 24, 4
 
-    def render_accum(accum, shard_index, shard_count):
-        prm = pkg.make_params(spp, "mis", "sobol", shard_index=shard_index, shard_count=shard_count)
-        a = accum.numpy()
-        orc.render_accum(sc, cam, prm, threads=2, accum=a)
+    def render_slice(s0, s1):
+        def render_accum(accum, shard_index, shard_count):
+            prm = pkg.make_params(spp, "mis", "sobol", shard_index=shard_index, shard_count=shard_count)
+            a = accum.numpy()
+            orc.render_accum(sc, cam, prm, s0, s1, threads=2, accum=a)
+        return render_accum
+    render_accum = render_slice(0, spp)
 
+    # the bench's job shape: two steps (sample indices [0,2) then [2,4)) into the rank-local film, then ONE film reduce
     accum = torch.zeros((H, W, 3), dtype=torch.float32)
-    mg.render_frame_sharded(render_accum, accum, rank, world)
+    mg.render_frame_sharded(render_slice(0, 2), accum, rank, world, reduce=False)
+    mg.render_frame_sharded(render_slice(2, 4), accum, rank, world, reduce=False)
+    mg.reduce_film(accum, world)
     t = mg.max_over_ranks(1.0 + rank, world, "cpu")
     assert t == float(world)          # MAX over ranks
     if rank == 0:
         full = torch.zeros((H, W, 3), dtype=torch.float32)
-        render_accum(full, 0, 1)
+        render_slice(0, 2)(full, 0, 1)      # same slice order as above: float sums are order-sensitive
+        render_slice(2, 4)(full, 0, 1)
+        one = torch.zeros((H, W, 3), dtype=torch.float32)
+        render_accum(one, 0, 1)
+        assert np.allclose(one.numpy(), full.numpy(), rtol=1e-5, atol=1e-6)
         np.save(out_path, np.stack([accum.numpy(), full.numpy()]))
     dist.barrier()
     dist.destroy_process_group()

@@ -27,7 +27,7 @@ out = collections.OrderedDict()
 for f in sorted(glob.glob(sys.argv[1] + "/p*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "pt_kernel<false, false>" in r["Kernel_Name"]:
+        if "pt_kernel<false, false" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         out[k] = sum(v) / len(v)

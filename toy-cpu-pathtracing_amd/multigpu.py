@@ -16,7 +16,15 @@ def render_frame_sharded(render_accum, accum, rank, world, reduce=True):
     """render_accum(accum_tensor, shard_index, shard_count) adds this rank's tiles into `accum` (a torch tensor on the
     rank's device).  Returns the reduced tensor on rank 0 (other ranks: their partial)."""
     render_accum(accum, **shard_of(rank, world))
-    if world > 1 and reduce:
+    if reduce:
+        reduce_film(accum, world)
+    return accum
+
+
+def reduce_film(accum, world):
+    """The job's single film exchange: sum the rank-local linear films onto rank 0 (tiles are disjoint, so the sum is
+    exact: every pixel has one non-zero contributor).  RCCL over xGMI for device tensors, gloo on the CPU."""
+    if world > 1:
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
     return accum
 
