@@ -106,6 +106,11 @@ typedef struct mi355pt_stats {
     uint64_t phase_cycles[10];
     double kernel_ms; /* device time of the path-tracing launch(es), HIP events on the launch stream */
     uint32_t launches;
+    /* diagnostic (collect_stats only): wave-level step counts, to compare with the per-lane counts above
+     * (lane utilisation of a stage = lane count / (64 * wave count)): 0 closest-hit node steps, 1 closest-hit triangle
+     * steps, 2 any-hit node steps, 3 any-hit triangle steps, 4 iterations of the wave state machine, 5 lanes shaded
+     * (summed over iterations), 6 lanes with a shadow ray, 7 spare */
+    uint64_t wave_steps[8];
 } mi355pt_stats;
 
 /* ---------------- scene construction ---------------- */

@@ -21,7 +21,7 @@ def test_struct_layouts_match_header(pkg):
     assert ctypes.sizeof(f.MaterialDesc) == 4 + 20 + 4 + 4 + 4 + 20 + 4 + 4 + 5 * 4 + 20
     assert ctypes.sizeof(f.Camera) == 48
     assert ctypes.sizeof(f.Params) == 36
-    assert ctypes.sizeof(f.Stats) == 11 * 8 + 10 * 8 + 8 + 8
+    assert ctypes.sizeof(f.Stats) == 11 * 8 + 10 * 8 + 8 + 8 + 8 * 8
 
 
 def test_host_only_entry_points(pkg):

@@ -44,11 +44,15 @@ best = min(ms[1:])
 rate = a.width * a.height * a.slice / best / 1e3
 prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=1, max_depth=a.max_depth)
 st = pkg.ffi.Stats()
-prod.render_accum_device(sc, cam, prm2, 0, 4, d_acc.value, None, stats=st)
+prod.render_accum_device(sc, cam, prm2, 0, a.slice, d_acc.value, None, stats=st)
 d = st.as_dict()
 ph = d["phase_cycles"]
 tot = max(ph[5], 1)
 names = ["regen", "closest", "shade", "shadow", "film", "loop", "sh_surface", "sh_bsdf", "sh_nee"]
 print(json.dumps({"tag": a.tag, "scene": a.scene, "Msamples_s": round(rate, 1), "ms": [round(x, 2) for x in ms],
                   "phase_share": {k: round(v / tot, 3) for k, v in zip(names, ph[:9]) if k != "loop"},
+                  "lane_util": (lambda w: {"closest_nodes": round(d["nodes_closest"] / max(64 * w[0], 1), 3), "closest_tris": round(d["tris_closest"] / max(64 * w[1], 1), 3),
+                                           "shadow_nodes": round(d["nodes_shadow"] / max(64 * w[2], 1), 3), "shadow_tris": round(d["tris_shadow"] / max(64 * w[3], 1), 3),
+                                           "shade": round(w[5] / max(64 * w[4], 1), 3), "shadow_lanes": round(w[6] / max(64 * w[4], 1), 3),
+                                           "wave_steps_per_iter": [round(x / max(w[4], 1), 2) for x in w[:4]]})(d["wave_steps"]),
                   "per_sample": {k: round(d[k] / max(d["samples"], 1), 2) for k in ("closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow", "bounces")}}))

@@ -21,6 +21,7 @@ f = np.array([0, -0.9, -3.2]); f /= np.linalg.norm(f); s = np.cross(f, [0, 1, 0]
 d = (d_cam[:, :1] * s + d_cam[:, 1:2] * u - d_cam[:, 2:3] * (-f)).astype(np.float32)
 d = (d_cam[:, :1] * s + d_cam[:, 1:2] * u + d_cam[:, 2:3] * (-f)).astype(np.float32)
 o = np.zeros_like(d)
+os.environ["MI355PT_TRAV"] = "1"
 t1, inst, tri, n = sc.probe_intersect(o, d)           # coherent
 hit = t1 > 0
 p = o[hit] + d[hit] * t1[hit, None]
@@ -29,7 +30,19 @@ d2 = rng.normal(size=p.shape).astype(np.float32); d2 /= np.linalg.norm(d2, axis=
 flip = np.sum(d2 * n[hit], 1) * np.sum(-d[hit] * n[hit], 1) < 0
 d2[flip] *= -1
 o2 = (p + n[hit] * np.sign(np.sum(-d[hit] * n[hit], 1))[:, None] * 1e-4).astype(np.float32)
-t2, *_ = sc.probe_intersect(o2, d2)                   # incoherent, same tile order
 perm = rng.permutation(o2.shape[0])
-t3, *_ = sc.probe_intersect(o2[perm], d2[perm])       # incoherent, shuffled across tiles
-print("rays", d.shape[0], o2.shape[0], "hit frac", hit.mean(), (t2 > 0).mean())
+REP = int(os.environ.get("RAY_REP", "8"))
+sets = {"coherent": (np.tile(o, (REP, 1)), np.tile(d, (REP, 1))), "incoherent_tile_order": (np.tile(o2, (REP, 1)), np.tile(d2, (REP, 1))),
+        "incoherent_shuffled": (np.tile(o2[perm], (REP, 1)), np.tile(d2[perm], (REP, 1)))}
+res = {}
+for mode in os.environ.get("RAY_MODES", "1,2").split(","):
+    os.environ["MI355PT_TRAV"] = mode[0]
+    if len(mode) > 1:
+        os.environ["MI355PT_PROBE_LDS"] = mode[2:]       # e.g. "1:13000" = lock-step with 13 KB extra LDS per wave
+    for k, (oo, dd) in sets.items():
+        tt, ii, tr, _ = sc.probe_intersect(oo, dd)
+        res[(mode, k)] = (tt, tr)
+        print("mode", mode, k, "rays", oo.shape[0], "hit frac", round(float((tt > 0).mean()), 4), flush=True)
+for k in sets:
+    if ("1", k) in res and ("2", k) in res:
+        print(k, "dyn vs lockstep identical t:", np.array_equal(res[("1", k)][0], res[("2", k)][0]), "tri:", np.array_equal(res[("1", k)][1], res[("2", k)][1]))

@@ -313,6 +313,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
             stats->tris_shadow = h.tris_shadow; stats->closest_hits = h.closest_hits; stats->bounces = h.bounces;
             stats->spectrum_evals = h.spectrum_evals; stats->textured_lookups = h.textured_lookups;
             for (int i = 0; i < 10; ++i) stats->phase_cycles[i] = h.phase_cycles[i];
+            for (int i = 0; i < 8; ++i) stats->wave_steps[i] = h.wave_steps[i];
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }

@@ -157,6 +157,7 @@ struct DevStats {
     unsigned long long samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;
     unsigned long long closest_hits, bounces, spectrum_evals, textured_lookups;
     unsigned long long phase_cycles[10];
+    unsigned long long wave_steps[8];
 };
 
 }  // namespace pt

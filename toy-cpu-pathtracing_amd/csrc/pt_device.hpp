@@ -293,7 +293,9 @@ PT_DEV void rgb2spec_lookup(const DevScene& sc, const float enc[3], float c[3]) 
 struct StatCounters {
     uint32_t closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow, closest_hits, bounces, spectrum_evals,
         textured_lookups, samples;
+    uint32_t w[8];      // wave-level step counts (incremented by the first active lane only), mi355pt_stats.wave_steps
 };
+PT_DEV bool wave_leader() { return __builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u; }
 
 // SpectrumParameter::sample(uv).sample(lambda)  (parameter.rs:38-47, spectrum.rs:32-46)
 template <bool STATS, bool TEX = true>
@@ -410,7 +412,7 @@ PT_DEV bool trace_closest(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_
             const float4* q = (const float4*)(sc.nodes + cur);
             float4 nx = q[0], ny = q[1], nz = q[2];
             int2 ch = *(const int2*)(q + 3);
-            if (STATS) st.nodes_closest++;
+            if (STATS) { st.nodes_closest++; if (wave_leader()) st.w[0]++; }
             float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
             float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
             float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
@@ -435,7 +437,7 @@ PT_DEV bool trace_closest(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_
             for (uint32_t i = 0; i < cnt; ++i) {
                 TriVerts tv = load_tri(sc.tris, first + i);
                 float t, b0, b1, b2;
-                if (STATS) st.tris_closest++;
+                if (STATS) { st.tris_closest++; if (wave_leader()) st.w[1]++; }
                 if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
                     if (!found || t < t_best) { found = true; t_best = t; hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = first + i; }
                 }
@@ -460,7 +462,7 @@ PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* s
             const float4* q = (const float4*)(sc.nodes + cur);
             float4 nx = q[0], ny = q[1], nz = q[2];
             int2 ch = *(const int2*)(q + 3);
-            if (STATS) st.nodes_shadow++;
+            if (STATS) { st.nodes_shadow++; if (wave_leader()) st.w[2]++; }
             float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
             float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
             float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
@@ -480,7 +482,7 @@ PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* s
             for (uint32_t i = 0; i < cnt; ++i) {
                 TriVerts tv = load_tri(sc.tris, first + i);
                 float t, b0, b1, b2;
-                if (STATS) st.tris_shadow++;
+                if (STATS) { st.tris_shadow++; if (wave_leader()) st.w[3]++; }
                 if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_max, tv, t, b0, b1, b2)) return true;
             }
         }
@@ -488,6 +490,101 @@ PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* s
         --sp; cur = (int32_t)stack[sp * 64];
     }
     return false;
+}
+
+// Any hit with DEFERRED, DENSE triangle tests (wave-cooperative; every lane of the wave must call it, `want` = this lane has
+// a ray).  In the plain loop above a wave spends most of its any-hit VALU time on triangle steps executed for the one or
+// two straggler lanes that happen to sit in a leaf (measured: 24 triangle steps per wave iteration at 3.7 % lane use).
+// Here lanes never test triangles themselves: a lane that reaches a leaf appends (triangle, lane) pairs to a per-wave ring
+// in LDS and keeps traversing; whenever 64 pairs are queued, the whole wave tests them at once — lane i takes pair i,
+// fetches the owner's ray with ds_bpermute and runs the same intersect_triangle().  Any-hit results are order independent
+// (exists a hit in (0, t_max]), so the outcome is identical to trace_any; an occluded lane stops at the next flush.
+constexpr uint32_t ANY_RING = 256;            // entries; a step appends <= 2 per lane, a flush leaves < 64 behind
+struct AnyLds { uint32_t* ring; uint32_t* occl; };   // ring[ANY_RING] (tri | owner << 26), occl[2] (bit per lane)
+
+template <bool STATS>
+PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bool want, uint32_t* stack, uint32_t lane, const AnyLds& L,
+                               StatCounters& st) {
+    if (!want) { rd = mk3(0.0f, 0.0f, 1.0f); ro = mk3(0.0f, 0.0f, 0.0f); t_max = 0.0f; }
+    RaySetup rs = setup_ray(rd);
+    const uint32_t kpack = (uint32_t)rs.kx | ((uint32_t)rs.ky << 2) | ((uint32_t)rs.kz << 4);
+    if (lane < 2) L.occl[lane] = 0u;
+    __syncthreads();
+    int sp = 0;
+    int32_t cur = sc.root;
+    uint32_t leaf_off = 0;                    // triangles of the current leaf already queued
+    bool done = !want;
+    uint32_t head = 0, tail = 0;              // wave-uniform ring cursors
+    if (STATS && want) st.shadow_rays++;
+
+    auto flush = [&](uint32_t n) {            // test ring entries [head, head + n), n <= 64
+        const bool valid = lane < n;
+        const uint32_t e = valid ? L.ring[(head + lane) & (ANY_RING - 1u)] : (lane << 26);
+        const uint32_t owner = e >> 26, tri = e & 0x03ffffffu;
+        f3 o2 = mk3(__shfl(ro.x, owner), __shfl(ro.y, owner), __shfl(ro.z, owner));
+        f3 d2 = mk3(__shfl(rd.x, owner), __shfl(rd.y, owner), __shfl(rd.z, owner));
+        float tm = __shfl(t_max, owner);
+        uint32_t kp = __shfl(kpack, owner);
+        float sx = __shfl(rs.sx, owner), sy = __shfl(rs.sy, owner), sz = __shfl(rs.sz, owner);
+        if (valid) {
+            TriVerts tv = load_tri(sc.tris, tri);
+            float t, b0, b1, b2;
+            if (STATS) { st.tris_shadow++; if (wave_leader()) st.w[3]++; }
+            if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, tm, tv, t, b0, b1, b2))
+                atomicOr(&L.occl[owner >> 5], 1u << (owner & 31u));
+        }
+        head += n;
+        __syncthreads();
+        if ((L.occl[lane >> 5] >> (lane & 31u)) & 1u) done = true;    // early out for lanes found occluded
+    };
+
+    for (;;) {
+        if (!done && cur >= 0) {
+            const float4* q = (const float4*)(sc.nodes + cur);
+            float4 nx = q[0], ny = q[1], nz = q[2];
+            int2 ch = *(const int2*)(q + 3);
+            if (STATS) { st.nodes_shadow++; if (wave_leader()) st.w[2]++; }
+            float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
+            float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
+            float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
+            float l1y = (ny.y - ro.y) * rs.inv.y, h1y = (ny.w - ro.y) * rs.inv.y;
+            float l0z = (nz.x - ro.z) * rs.inv.z, h0z = (nz.z - ro.z) * rs.inv.z;
+            float l1z = (nz.y - ro.z) * rs.inv.z, h1z = (nz.w - ro.z) * rs.inv.z;
+            float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+            float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_max));
+            float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+            float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_max));
+            bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+            if (hit0 && hit1) { stack[sp * 64] = (uint32_t)ch.y; ++sp; cur = ch.x; }
+            else if (hit0) cur = ch.x;
+            else if (hit1) cur = ch.y;
+            else if (sp == 0) done = true;
+            else { --sp; cur = (int32_t)stack[sp * 64]; }
+        }
+        // lanes sitting in a leaf queue up to two of its triangles per step, then move on
+        const bool at_leaf = !done && cur < 0;
+        const unsigned long long m1 = __ballot(at_leaf);
+        if (m1 != 0ull) {
+            uint32_t first = 0, rem = 0;
+            if (at_leaf) { first = leaf_first(cur) + leaf_off; rem = leaf_count(cur) - leaf_off; }
+            const uint32_t a = rem < 2u ? rem : 2u;
+            const unsigned long long m2 = __ballot(a == 2u);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t pos = tail + (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
+            if (a >= 1u) L.ring[pos & (ANY_RING - 1u)] = first | (lane << 26);
+            if (a == 2u) L.ring[(pos + 1u) & (ANY_RING - 1u)] = (first + 1u) | (lane << 26);
+            tail += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+            if (at_leaf) {
+                if (rem > 2u) leaf_off += 2u;
+                else { leaf_off = 0u; if (sp == 0) done = true; else { --sp; cur = (int32_t)stack[sp * 64]; } }
+            }
+            __syncthreads();
+            while (tail - head >= 64u) flush(64u);
+        }
+        if (__ballot(!done) == 0ull) break;
+    }
+    if (tail != head) flush(tail - head);     // stragglers' last pairs (tail - head < 64 here)
+    return ((L.occl[lane >> 5] >> (lane & 31u)) & 1u) != 0u;
 }
 
 }  // namespace pt

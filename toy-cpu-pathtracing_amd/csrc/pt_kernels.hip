@@ -9,10 +9,14 @@
 //    regenerates the next sample of its pixel when the path ends (in-register compaction);
 //  * inside a wave the path loop is a lock-step state machine: every iteration all 64 lanes trace one closest-hit
 //    ray together, shade together, trace one shadow ray together; a lane whose path ended regenerates the next
-//    sample of its pixel at the top of the next iteration.  Three alternatives were built and measured slower on
-//    MI355X: a lane pool with vote-driven batched shading (516 vs 654 Msamples/s), one merged
-//    shadow+closest traversal loop per iteration (670 vs 851) and persistent traversal with dynamic ray fetch
-//    (1.2-3 vs 5-12 Grays/s in the stand-alone traversal kernel): the simple tight loops win;
+//    sample of its pixel at the top of the next iteration.  Alternatives built and measured on MI355X:
+//    a lane pool with vote-driven batched shading (516 vs 654 Msamples/s), one merged shadow+closest traversal loop
+//    per iteration (670 vs 851), packed-f32 slab tests (-5 %): slower.  Persistent traversal with dynamic ray fetch
+//    (probe_intersect_dyn_kernel below, wave-local ray batches): 1.16-1.55x on the stand-alone traversal kernel for
+//    incoherent rays, 0.6x for coherent ones — not enough to pay for streaming path state through HBM;
+//  * shadow rays use deferred, dense triangle tests (trace_any_deferred, pt_device.hpp): lanes only walk nodes and
+//    queue (triangle, lane) pairs in an LDS ring, the wave tests 64 pairs at a time (any-hit is order independent).
+//    Measured on C2: any-hit triangle steps per wave iteration 24 at 3.7 % lane use -> 1.8 at 72 %, +4-5 % Msamples/s;
 //  * BVH traversal keeps the per-lane stack in LDS (stack[level][lane], conflict-free) and the
 //    MurmurHash(dimension, seed) table of the Sobol sampler in LDS.
 #include <hip/hip_runtime.h>
@@ -61,8 +65,12 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
     atomicAdd(&stats->bounces, (unsigned long long)st.bounces);
     atomicAdd(&stats->spectrum_evals, (unsigned long long)st.spectrum_evals);
     atomicAdd(&stats->textured_lookups, (unsigned long long)st.textured_lookups);
+    for (int i = 0; i < 8; ++i) if (st.w[i]) atomicAdd(&stats->wave_steps[i], (unsigned long long)st.w[i]);
 }
 
+#ifndef PT_ANY_DEFERRED
+#define PT_ANY_DEFERRED 1
+#endif
 template <bool STATS, bool PROBE, uint32_t FEAT>
 __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, unsigned* __restrict__ work_counter,
@@ -72,6 +80,11 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
     __shared__ uint64_t s_hash[HASH_TABLE_DIMS];
     __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
     __shared__ unsigned s_work;
+#if PT_ANY_DEFERRED
+    __shared__ uint32_t s_ring[ANY_RING];
+    __shared__ uint32_t s_occl[2];
+    const AnyLds any_lds{s_ring, s_occl};
+#endif
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < (uint32_t)HASH_TABLE_DIMS; i += 64) s_hash[i] = dim_hash_tab[i];
     __syncthreads();
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
         if (STATS) t_loop0 = __builtin_amdgcn_s_memtime();
         while (__any(active)) {
             unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
-            if (STATS) ts0 = __builtin_amdgcn_s_memtime();
+            if (STATS) { ts0 = __builtin_amdgcn_s_memtime(); if (lane == 0) st.w[4]++; if (active) st.w[5]++; }
             if (active && need_new) { regen_path<STATS>(P, sctx, cam, job.px, job.py, s_cur, st); need_new = false; }
             if (STATS) ts1 = __builtin_amdgcn_s_memtime();
             Hit hit{};
@@ -117,13 +130,25 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
             ShadowReq sh{};
             if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
             if (STATS) ts3 = __builtin_amdgcn_s_memtime();
+#if PT_ANY_DEFERRED
+            if (__any(sh.on)) {
+                if (STATS && sh.on) st.w[6]++;
+                bool occluded = trace_any_deferred<STATS>(sc, sh.o, sh.d, sh.t, sh.on, stack, lane, any_lds, st);
+                if (sh.on && !occluded) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
+                }
+            }
+#else
             if (sh.on) {
+                if (STATS) st.w[6]++;
                 bool occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st);
                 if (!occluded) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
                 }
             }
+#endif
             if (STATS) ts4 = __builtin_amdgcn_s_memtime();
             if (active && end_path) {
                 film_add<PROBE>(P, sc, prm, acc_r, acc_g, acc_b, pout, work * 64 + lane);
@@ -219,6 +244,113 @@ __global__ __launch_bounds__(64) void probe_occluded_kernel(DevScene sc, const f
     out[i] = trace_any<false>(sc, ro, rd, tmax[i], s_stack + threadIdx.x, st) ? 1 : 0;
 }
 
+
+// ---- experiment (MI355PT_TRAV=2, probe_intersect only): persistent traversal with dynamic ray fetch -----------------
+// Waves own a contiguous batch of rays (one global atomic per DYN_BATCH rays); a lane whose ray finished takes the next
+// ray of the batch, so the wave does not idle through the tail of its slowest ray.  Leaves are postponed until
+// DYN_LEAF_MIN lanes hold one (or nobody has a node left).
+#ifndef DYN_BATCH
+#define DYN_BATCH 1024u
+#endif
+#ifndef DYN_LEAF_MIN
+#define DYN_LEAF_MIN 16
+#endif
+#ifndef DYN_REFILL_MIN
+#define DYN_REFILL_MIN 12
+#endif
+#ifndef DYN_WAVES
+#define DYN_WAVES 8
+#endif
+__global__ __launch_bounds__(64, DYN_WAVES) void probe_intersect_dyn_kernel(DevScene sc, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
+                                                                 float* __restrict__ out_t, uint32_t* __restrict__ out_inst,
+                                                                 uint32_t* __restrict__ out_tri, unsigned* __restrict__ counter) {
+    __shared__ uint32_t s_stack[STACK_DEPTH * 64];
+    uint32_t* stack = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    bool have = false, pool_empty = false;
+    uint32_t next = 0, end = 0;          // wave-uniform: the batch this wave is serving
+    uint32_t ray = 0;
+    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+    RaySetup rs{};
+    float t_best = 0.0f;
+    int32_t cur = 0; int sp = 0;
+    uint32_t best_tri = 0; bool found = false;
+    for (;;) {
+        // ---- refill: idle lanes take the next rays of the wave's batch ----
+        unsigned long long idle = __ballot(!have);
+        if (idle != 0ull) {
+            if (next >= end && !pool_empty) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(counter, DYN_BATCH);
+                base = __shfl(base, 0);
+                if (base >= n) pool_empty = true; else { next = base; end = min(base + DYN_BATCH, n); }
+            }
+            uint32_t avail = end - next;
+            if (avail != 0u) {
+                uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!have && rank < avail) {
+                    uint32_t r = next + rank;
+                    ray = r; have = true;
+                    ro = mk3(o[3 * r], o[3 * r + 1], o[3 * r + 2]); rd = mk3(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
+                    rs = setup_ray(rd); t_best = 3.402823466e+38f; cur = sc.root; sp = 0; found = false;
+                }
+                next += min((uint32_t)__popcll(idle), avail);
+            }
+        }
+        if (__ballot(have) == 0ull) { if (pool_empty || next >= end) { if (pool_empty) break; } continue; }
+        // ---- traversal quantum ----
+        for (int q = 0; q < 32; ++q) {
+            bool fin = false;
+            if (have && cur >= 0) {
+                const float4* qn = (const float4*)(sc.nodes + cur);
+                float4 nx = qn[0], ny = qn[1], nz = qn[2];
+                int2 ch = *(const int2*)(qn + 3);
+                float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
+                float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
+                float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
+                float l1y = (ny.y - ro.y) * rs.inv.y, h1y = (ny.w - ro.y) * rs.inv.y;
+                float l0z = (nz.x - ro.z) * rs.inv.z, h0z = (nz.z - ro.z) * rs.inv.z;
+                float l1z = (nz.y - ro.z) * rs.inv.z, h1z = (nz.w - ro.z) * rs.inv.z;
+                float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+                float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_best));
+                float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+                float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_best));
+                bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+                if (hit0 && hit1) { bool first0 = n0 <= n1; stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp; cur = first0 ? ch.x : ch.y; }
+                else if (hit0) cur = ch.x;
+                else if (hit1) cur = ch.y;
+                else if (sp == 0) fin = true;
+                else { --sp; cur = (int32_t)stack[sp * 64]; }
+            }
+            const bool at_leaf = have && !fin && cur < 0;
+            const unsigned long long m_leaf = __ballot(at_leaf);
+            if (m_leaf != 0ull && (__popcll(m_leaf) >= DYN_LEAF_MIN || __ballot(have && !fin && cur >= 0) == 0ull)) {
+                if (at_leaf) {
+                    uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        TriVerts tv = load_tri(sc.tris, first + i);
+                        float t, b0, b1, b2;
+                        if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
+                            if (!found || t < t_best) { found = true; t_best = t; best_tri = first + i; }
+                        }
+                    }
+                    if (sp == 0) fin = true; else { --sp; cur = (int32_t)stack[sp * 64]; }
+                }
+            }
+            if (fin) {
+                const float4* qs = (const float4*)(sc.shade + best_tri);
+                out_t[ray] = found ? t_best : -1.0f;
+                out_inst[ray] = found ? __float_as_uint(qs[4].w) : 0xffffffffu;
+                out_tri[ray] = found ? __float_as_uint(qs[5].z) : 0xffffffffu;
+                have = false;
+            }
+            const unsigned long long m_have = __ballot(have);
+            if (m_have == 0ull) break;
+            if (64 - __popcll(m_have) >= DYN_REFILL_MIN && !(pool_empty && next >= end)) break;   // refill
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (host side, called from api.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -264,7 +396,21 @@ hipError_t launch_probe_sobol(uint32_t width, uint32_t seed, uint32_t log2_spp, 
 }
 hipError_t launch_probe_intersect(const DevScene& sc, const float* o, const float* d, uint32_t n, float* t, uint32_t* inst, uint32_t* tri, float* nrm,
                                   hipStream_t stream) {
-    hipLaunchKernelGGL(probe_intersect_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, nrm);
+    const char* mode = getenv("MI355PT_TRAV");
+    if (mode && mode[0] == '2') {
+        static unsigned* d_ctr = nullptr;
+        if (!d_ctr && hipMalloc((void**)&d_ctr, sizeof(unsigned)) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_ctr, 0, sizeof(unsigned), stream);
+        if (nrm) (void)hipMemsetAsync(nrm, 0, sizeof(float) * 3 * (size_t)n, stream);
+        int nb = 0, dev = 0; hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, probe_intersect_dyn_kernel, 64, 0);
+        int grid = std::min<int>((int)((n + 63) / 64), nb * prop.multiProcessorCount);
+        hipLaunchKernelGGL(probe_intersect_dyn_kernel, dim3(grid), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, d_ctr);
+        return hipGetLastError();
+    }
+    const char* lds = getenv("MI355PT_PROBE_LDS");   // experiment: extra dynamic LDS per wave to throttle occupancy
+    hipLaunchKernelGGL(probe_intersect_kernel, dim3((n + 63) / 64), dim3(64), lds ? atoi(lds) : 0, stream, sc, o, d, n, t, inst, tri, nrm);
     return hipGetLastError();
 }
 hipError_t launch_probe_occluded(const DevScene& sc, const float* o, const float* d, const float* tmax, uint32_t n, uint8_t* out, hipStream_t stream) {

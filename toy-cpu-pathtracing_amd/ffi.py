@@ -65,11 +65,13 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest",
                                           "nodes_shadow", "tris_shadow", "closest_hits", "bounces", "spectrum_evals",
-                                          "textured_lookups")] + [("phase_cycles", C.c_uint64 * 10), ("kernel_ms", C.c_double), ("launches", C.c_uint32)]
+                                          "textured_lookups")] + [("phase_cycles", C.c_uint64 * 10), ("kernel_ms", C.c_double), ("launches", C.c_uint32),
+                                                ("wave_steps", C.c_uint64 * 8)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
         d["phase_cycles"] = list(self.phase_cycles)
+        d["wave_steps"] = list(self.wave_steps)
         return d
 
 
