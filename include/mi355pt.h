@@ -49,13 +49,17 @@ typedef struct mi355pt_spectrum {
 } mi355pt_spectrum;
 
 /* ---- materials: scene::{LambertMaterial, EmissiveMaterial, GlassMaterial, PlasticMaterial,
- *      SimpleClearcoatPbrMaterial}::new  (scene/src/material/impls/) ---- */
+ *      SimpleClearcoatPbrMaterial, MetalMaterial, SimplePbrMaterial}::new  (scene/src/material/impls/) ---- */
 enum {
     MI355PT_MAT_LAMBERT = 0,   /* color = albedo, normal_tex                       lambert_material.rs:17-27   */
     MI355PT_MAT_EMISSIVE = 1,  /* color = radiance, intensity                      emissive_material.rs:17-29  */
     MI355PT_MAT_GLASS = 2,     /* eta (LUT470), normal_tex, thin, roughness        glass_material.rs:34-49     */
     MI355PT_MAT_PLASTIC = 3,   /* eta (constant), color, normal_tex, thin, rough.  plastic_material.rs:17-38    */
-    MI355PT_MAT_CLEARCOAT = 4  /* simple_pbr_clearcoat_material.rs:17-75                                       */
+    MI355PT_MAT_CLEARCOAT = 4, /* simple_pbr_clearcoat_material.rs:17-75                                       */
+    MI355PT_MAT_METAL = 5,     /* MetalMaterial::new(MetalType, normal, roughness): eta + k (LUT470 = presets::au_eta()/au_k() ...),
+                                * normal_tex, roughness (alpha = roughness^2)           metal_material.rs:17-92      */
+    MI355PT_MAT_SIMPLE_PBR = 6 /* SimplePbrMaterial::new(base_color=color, metallic, roughness, normal, ior)
+                                * = the clearcoat material's base layer                 simple_pbr_material.rs:14-53 */
 };
 typedef struct mi355pt_material_desc {
     uint32_t type;
@@ -70,6 +74,7 @@ typedef struct mi355pt_material_desc {
      * clearcoat_ior, clearcoat_roughness, clearcoat_tint, clearcoat_thickness) */
     float metallic, ior, clearcoat_ior, clearcoat_roughness, clearcoat_thickness;
     mi355pt_spectrum clearcoat_tint;
+    mi355pt_spectrum k;     /* metal only: extinction coefficient */
 } mi355pt_material_desc;
 
 /* ---- camera: renderer::Camera::new + set_look_to (renderer/src/camera.rs:27-49) ---- */

@@ -254,6 +254,89 @@ struct DielectricBsdf {
     }
 };
 
+
+// ---------------- ConductorBsdf (bsdf/conductor.rs) ----------------
+struct Cplx { float re, im; };                                                    // :14-84
+static inline Cplx cadd(Cplx a, Cplx b) { return {a.re + b.re, a.im + b.im}; }
+static inline Cplx csub(Cplx a, Cplx b) { return {a.re - b.re, a.im - b.im}; }
+static inline Cplx cmul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+static inline Cplx cscale(Cplx a, float s) { return {a.re * s, a.im * s}; }
+static inline Cplx cdiv(Cplx a, Cplx b) {
+    float den = b.re * b.re + b.im * b.im;
+    if (den == 0.0f) return {0.0f, 0.0f};
+    return {(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+}
+static inline float cnorm(Cplx a) { return a.re * a.re + a.im * a.im; }           // |z|^2
+static inline Cplx csqrt(Cplx a) {                                                // polar form, :29-36
+    float r = std::sqrt(a.re * a.re + a.im * a.im);
+    float theta = std::atan2(a.im, a.re);
+    float sr = std::sqrt(r), ht = theta * 0.5f;
+    return {sr * std::cos(ht), sr * std::sin(ht)};
+}
+static inline SS fresnel_complex(float cos_i, SS eta, SS k) {                      // :92-124
+    cos_i = std::fmin(std::fmax(cos_i, 0.0f), 1.0f);
+    SS out;
+    for (int i = 0; i < 4; ++i) {
+        Cplx ce{eta.v[i], k.v[i]};
+        float sin2_i = 1.0f - cos_i * cos_i;
+        Cplx sin2_t = cdiv(Cplx{sin2_i, 0.0f}, cmul(ce, ce));
+        Cplx cos_t = csqrt(csub(Cplx{1.0f, 0.0f}, sin2_t));
+        Cplx r_parl = cdiv(csub(cscale(ce, cos_i), cos_t), cadd(cscale(ce, cos_i), cos_t));
+        Cplx r_perp = cdiv(csub(Cplx{cos_i, 0.0f}, cmul(ce, cos_t)), cadd(Cplx{cos_i, 0.0f}, cmul(ce, cos_t)));
+        out.v[i] = (cnorm(r_parl) + cnorm(r_perp)) * 0.5f;
+    }
+    return out;
+}
+struct ConductorBsdf {
+    SS eta, k; float ax, ay;
+    DielectricBsdf ggx() const { return DielectricBsdf(SS::one(), true, false, ax, ay); }   // same Trowbridge-Reitz code (:151-250)
+    bool effectively_smooth() const { return std::fmax(ax, ay) < 1e-3f; }
+    static bool half_vec(V3 wo, V3 wi, V3* wm) {                                  // common.rs:47-57
+        V3 h = wo + wi;
+        if (length_squared(h) == 0.0f) return false;
+        *wm = normalize(h); return true;
+    }
+    SS torrance_sparrow(V3 wo, V3 wi, V3 wm) const {                              // :331-354
+        float co = std::fabs(wo.z), ci = std::fabs(wi.z);
+        if (co == 0.0f || ci == 0.0f) return SS::zero();
+        SS fr = fresnel_complex(std::fabs(dot(wo, wm)), eta, k);
+        DielectricBsdf g = ggx();
+        return fr * g.D(wm) * g.G(wo, wi) / (4.0f * co);
+    }
+    float pdf_microfacet(V3 wo, V3 wi) const {                                    // :414-439
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wm;
+        if (!half_vec(wo, wi, &wm)) return 0.0f;
+        float vis = ggx().Dw(wo, wm);
+        float jac = 4.0f * std::fabs(dot(wo, wm));
+        if (jac == 0.0f) return 0.0f;
+        return vis / jac;
+    }
+    bool sample(V3 wo, V2 uv, BsdfSample* out) const {                            // :257-329
+        if (wo.z == 0.0f) return false;
+        if (effectively_smooth()) {
+            V3 wi{-wo.x, -wo.y, wo.z};
+            if (wi.z == 0.0f) return false;
+            *out = BsdfSample{fresnel_complex(std::fabs(wi.z), eta, k), wi, 1.0f, ST_SPEC_REFL};
+            return true;
+        }
+        V3 wm = ggx().sample_wm(wo, uv);
+        V3 wi = reflect(wo, wm);
+        if (!same_hemisphere(wo, wi)) return false;
+        *out = BsdfSample{torrance_sparrow(wo, wi, wm), wi, pdf_microfacet(wo, wi), ST_GLOSSY_REFL};
+        return true;
+    }
+    SS evaluate(V3 wo, V3 wi) const {                                             // :356-395
+        if (effectively_smooth()) return SS::zero();
+        if (std::fabs(wo.z) == 0.0f || std::fabs(wi.z) == 0.0f) return SS::zero();
+        if (!same_hemisphere(wo, wi)) return SS::zero();
+        V3 wm;
+        if (!half_vec(wo, wi, &wm)) return SS::zero();
+        return torrance_sparrow(wo, wi, wm);
+    }
+    float pdf(V3 wo, V3 wi) const { return effectively_smooth() ? 0.0f : pdf_microfacet(wo, wi); }   // :397-412
+};
+
 // ---------------- GeneralizedSchlickBsdf, ScatterMode::R (bsdf/generalized_schlick.rs) ----------------
 // The clearcoat material only ever instantiates it with ScatterMode::R, entering = true, thin = false
 // (simple_pbr_clearcoat_material.rs:121-133,445-456,...), so only the reflection arms are restated.
@@ -454,6 +537,20 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
         ms.f = bs.f * att; ms.wi = wi_sh; ms.pdf = bs.pdf * (1.0f - fc); ms.sample_type = bs.type; ms.is_sampled = true;
         return ms;
     }
+    if (m.type == MAT_METAL) {                                               // metal_material.rs:96-148
+        SS eta = m.eta.sample(wl), k = m.k.sample(wl);
+        M4 tf = normal_map_transform(m, sp.uv);
+        M4 tf_inv = inverse(tf);
+        V3 wo_nm = transform_vector3(tf, wo);
+        float alpha = m.roughness * m.roughness;
+        ConductorBsdf bsdf{eta, k, alpha, alpha};
+        BsdfSample bs;
+        if (!bsdf.sample(wo_nm, uv, &bs)) return ms;
+        V3 wi_sh = transform_vector3(tf_inv, bs.wi);
+        if (signum(dot(sp.normal, wi_sh)) != signum(dot(sp.normal, wo))) return ms;
+        ms.f = bs.f; ms.wi = wi_sh; ms.pdf = bs.pdf; ms.sample_type = bs.type; ms.is_sampled = true;
+        return ms;
+    }
     if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:42-97
         SS albedo = scene.sample_spectrum_param(m.color, sp.uv, wl, ctr);
         M4 tf = normal_map_transform(m, sp.uv);
@@ -497,6 +594,14 @@ inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo
         SS att = Clearcoat::attenuation(cc.tint, m.cc_thickness, wo_nm.z) * Clearcoat::attenuation(cc.tint, m.cc_thickness, wi_nm.z);
         return cf * fc + sf * att * (1.0f - fc);
     }
+    if (m.type == MAT_METAL) {                                               // metal_material.rs:150-192
+        SS eta = m.eta.sample(wl), k = m.k.sample(wl);
+        M4 tf = normal_map_transform(m, sp.uv);
+        V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
+        if (signum(dot(sp.normal, wi)) != signum(dot(sp.normal, wo))) return SS::zero();
+        float alpha = m.roughness * m.roughness;
+        return ConductorBsdf{eta, k, alpha, alpha}.evaluate(wo_nm, wi_nm);
+    }
     if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:99-131
         SS albedo = scene.sample_spectrum_param(m.color, sp.uv, wl, ctr);
         M4 tf = normal_map_transform(m, sp.uv);
@@ -525,6 +630,13 @@ inline float MaterialEval::pdf(const Material& m, const Wavelengths& wl, V3 wo, 
         if (m.cc_thickness <= 0.0f) return cc.pdf_base(wo_nm, wi_nm);
         float fc = cc.coat_weight(wo_nm);
         return cc.coat().pdf_R(wo_nm, wi_nm) * fc + cc.pdf_base(wo_nm, wi_nm) * (1.0f - fc);
+    }
+    if (m.type == MAT_METAL) {                                               // metal_material.rs:194-229
+        M4 tf = normal_map_transform(m, sp.uv);
+        if (signum(dot(sp.normal, wi)) != signum(dot(sp.normal, wo))) return 0.0f;
+        V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
+        float alpha = m.roughness * m.roughness;
+        return ConductorBsdf{m.eta.sample(wl), m.k.sample(wl), alpha, alpha}.pdf(wo_nm, wi_nm);
     }
     if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:133-159
         M4 tf = normal_map_transform(m, sp.uv);

@@ -17,7 +17,7 @@ struct SpectrumParameter {
     int texture = -1;
 };
 
-enum MaterialType : uint32_t { MAT_LAMBERT = 0, MAT_EMISSIVE = 1, MAT_GLASS = 2, MAT_PLASTIC = 3, MAT_CLEARCOAT = 4 };
+enum MaterialType : uint32_t { MAT_LAMBERT = 0, MAT_EMISSIVE = 1, MAT_GLASS = 2, MAT_PLASTIC = 3, MAT_CLEARCOAT = 4, MAT_METAL = 5 };
 
 struct Material {
     uint32_t type = MAT_LAMBERT;
@@ -25,7 +25,8 @@ struct Material {
     int normal_tex = -1;           // NormalParameter::Texture
     bool normal_flip_y = false;
     float intensity = 1.0f;        // Emissive FloatParameter::Constant
-    Spectrum eta;                  // Glass: LUT spectrum; Plastic: constant
+    Spectrum eta;                  // Glass: LUT spectrum; Plastic: constant; Metal: real part of the index
+    Spectrum k;                    // Metal: extinction coefficient (presets::au_k() ...)
     bool thin = false;
     float roughness = 0.0f;
     // clearcoat (simple_pbr_clearcoat_material.rs): filled by the API when type == MAT_CLEARCOAT

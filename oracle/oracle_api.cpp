@@ -97,6 +97,11 @@ int ptoracle_scene_add_material(ptoracle_scene* s, const mi355pt_material_desc* 
     m.intensity = d->intensity;
     if (d->type == MI355PT_MAT_GLASS || d->type == MI355PT_MAT_PLASTIC) { if (!lower_spectrum(s, d->eta, &m.eta)) return -1; }
     m.thin = d->thin != 0; m.roughness = d->roughness;
+    if (d->type == MI355PT_MAT_METAL) { if (!lower_spectrum(s, d->eta, &m.eta) || !lower_spectrum(s, d->k, &m.k)) return -1; }
+    if (d->type == MI355PT_MAT_SIMPLE_PBR) {     // SimplePbrMaterial == the clearcoat material's base layer (thickness 0 takes that path)
+        m.type = MAT_CLEARCOAT; m.cc_metallic = d->metallic; m.cc_base_ior = d->ior; m.cc_thickness = 0.0f;
+        m.cc_tint = SpectrumParameter{}; 
+    }
     if (d->type == MI355PT_MAT_CLEARCOAT) {
         m.cc_metallic = d->metallic; m.cc_base_ior = d->ior; m.cc_ior = d->clearcoat_ior; m.cc_roughness = d->clearcoat_roughness;
         m.cc_thickness = d->clearcoat_thickness;
@@ -250,6 +255,8 @@ int ptoracle_probe_rgb2spec(ptoracle_scene* s, const float* rgb_enc, uint32_t n,
     for (uint32_t i = 0; i < n; ++i) s->scene.table.get_srgb_encoded(rgb_enc + 3 * i, out_c + 3 * i);
     return 0;
 }
+// fresnel_complex probe (bsdf/conductor.rs:92-124), one wavelength lane replicated
+float ptoracle_probe_fresnel_complex(float cos_i, float eta, float k) { return fresnel_complex(cos_i, SS::constant(eta), SS::constant(k)).v[0]; }
 int ptoracle_bvh_stats(ptoracle_scene* s, uint64_t* out /* tlas nodes, total blas nodes */) {
     out[0] = s->scene.tlas.nodes.size(); out[1] = 0;
     for (auto& g : s->scene.geometries) out[1] += g->bvh.nodes.size();

@@ -38,6 +38,8 @@ class Oracle(ffi.Backend):
         lib.ptoracle_reset_counters.argtypes = [C.c_void_p]
         lib.ptoracle_reset_counters.restype = None
         lib.ptoracle_scene_set_faithful.argtypes = [C.c_void_p, C.c_int]
+        lib.ptoracle_probe_fresnel_complex.argtypes = [C.c_float, C.c_float, C.c_float]
+        lib.ptoracle_probe_fresnel_complex.restype = C.c_float
         lib.ptoracle_probe_sobol_index.argtypes = [C.c_uint32] * 7 + [C.POINTER(C.c_uint64)]
         lib.ptoracle_sobol_matrices.argtypes = [C.POINTER(C.c_uint32)]
         lib.ptoracle_probe_rgb2spec.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float)]
@@ -86,6 +88,9 @@ class Oracle(ffi.Backend):
         out = np.zeros(104, dtype=np.uint32)
         self.lib.ptoracle_sobol_matrices(ffi._ptr(out, C.c_uint32))
         return out
+
+    def fresnel_complex(self, cos_i, eta, k):
+        return float(self.lib.ptoracle_probe_fresnel_complex(cos_i, eta, k))
 
     def rgb2spec(self, scene, rgb):
         rgb = np.ascontiguousarray(rgb, dtype=np.float32).reshape(-1, 3)

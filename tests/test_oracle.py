@@ -106,6 +106,22 @@ def test_pt_nee_mis_consistency(oracle, pkg):
     assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
 
 
+def test_conductor_fresnel_known_answers(oracle, pkg):
+    """fresnel_complex (bsdf/conductor.rs:92-124) against the closed forms: normal incidence R = ((n-1)^2+k^2)/((n+1)^2+k^2),
+    grazing incidence R = 1, k = 0 reduces to the real dielectric Fresnel; gold is yellow (R(600nm) >> R(450nm))."""
+    for n, k in ((0.2, 3.0), (1.5, 0.0), (1.1, 6.8), (0.05, 4.2)):
+        r0 = ((n - 1) ** 2 + k ** 2) / ((n + 1) ** 2 + k ** 2)
+        assert abs(oracle.fresnel_complex(1.0, n, k) - r0) <= 2e-6
+        assert abs(oracle.fresnel_complex(0.0, n, k) - 1.0) <= 2e-6
+    c, n = 0.6, 1.5                                                   # unpolarised dielectric Fresnel
+    ct = np.sqrt(1 - (1 - c * c) / (n * n))
+    rp, rs = (n * c - ct) / (n * c + ct), (c - n * ct) / (c + n * ct)
+    assert abs(oracle.fresnel_complex(c, n, 0.0) - 0.5 * (rp * rp + rs * rs)) <= 2e-6
+    p = pkg.scenes.presets()
+    au = lambda nm: oracle.fresnel_complex(1.0, float(p["au_eta"][nm - 360]), float(p["au_k"][nm - 360]))
+    assert au(600) > 0.85 and au(450) < 0.45
+
+
 def test_rgb2spec_round_trip_delta_e(oracle, pkg):
     """rgb_to_spec/tests/test.rs:224-320: 16^3 grid, RGB -> coefficients -> spectrum x D65 x CMF -> RGB, Delta E*ab <= 3
     (the reference only prints the violation count; here it is asserted for in-gamut, not-too-dark colours)."""

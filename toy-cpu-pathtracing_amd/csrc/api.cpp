@@ -245,6 +245,15 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
             if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, err);
             if ((rc = im.lower_spectrum(d->clearcoat_tint, &m.cc_tint, true, &err))) return fail(rc, "clearcoat tint: " + err);
             break;
+        case MI355PT_MAT_SIMPLE_PBR:      // SimplePbrMaterial == the clearcoat material's base layer: thickness 0 takes exactly that path
+            m.type = MT_CLEARCOAT; m.cc_thickness = 0.0f; m.cc_ior = 1.5f; m.cc_roughness = 0.0f;
+            m.cc_tint.kind = SPK_CONSTANT; m.cc_tint.c[0] = 1.0f;
+            if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, err);
+            break;
+        case MI355PT_MAT_METAL:
+            if ((rc = im.lower_spectrum(d->eta, &m.eta, false, &err))) return fail(rc, "eta: " + err);
+            if ((rc = im.lower_spectrum(d->k, &m.cc_tint, false, &err))) return fail(rc, "k: " + err);
+            break;
         default:
             return fail(MI355PT_E_INVALID, "material type not implemented on the device yet");
     }

@@ -79,7 +79,7 @@ struct DevSpectrum {
 };
 static_assert(sizeof(DevSpectrum) == 32, "spectrum param");
 
-enum : uint32_t { MT_LAMBERT = 0, MT_EMISSIVE = 1, MT_GLASS = 2, MT_PLASTIC = 3, MT_CLEARCOAT = 4 };
+enum : uint32_t { MT_LAMBERT = 0, MT_EMISSIVE = 1, MT_GLASS = 2, MT_PLASTIC = 3, MT_CLEARCOAT = 4, MT_METAL = 5 };
 struct alignas(16) DevMaterial {
     uint32_t type;
     uint32_t normal_tex;   // ~0 = none
@@ -89,7 +89,7 @@ struct alignas(16) DevMaterial {
     float cc_ior, cc_roughness, cc_thickness, pad0;
     DevSpectrum color;
     DevSpectrum eta;       // glass: LUT, plastic: constant
-    DevSpectrum cc_tint;
+    DevSpectrum cc_tint;   // clearcoat tint; metal: extinction coefficient k
 };
 static_assert(sizeof(DevMaterial) == 144, "material record");
 
@@ -151,7 +151,7 @@ struct DevParams {
 
 // Scene feature bits: the host picks the smallest kernel specialisation that covers the scene's materials, so a
 // Lambert-only Cornell box does not carry the registers and code of the clearcoat / dielectric / texture paths.
-enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_ALL = 31 };
+enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_METAL = 32, FEAT_ALL = 63 };
 
 struct DevStats {
     unsigned long long samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;

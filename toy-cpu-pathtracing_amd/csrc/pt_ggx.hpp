@@ -50,6 +50,30 @@ PT_DEV f3 ggx_sample_wm(float ax, float ay, f3 w, f2 u) {                       
 // generalized_schlick_fresnel with exponent 5, r90 = 1, tint = 1: r0 + (1 - r0) (1 - c)^5    (:92-116)
 PT_DEV float schlick_p5(float cos_theta) { float c = fminf(fmaxf(cos_theta, 0.0f), 1.0f); float o = 1.0f - c; float o2 = o * o; return o2 * o2 * o; }
 
+// fresnel_complex for one wavelength lane (bsdf/conductor.rs:14-124): complex arithmetic spelled out like the reference
+struct Cplx { float re, im; };
+PT_DEV Cplx cmul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+PT_DEV Cplx cdiv(Cplx a, Cplx b) {
+    float den = b.re * b.re + b.im * b.im;
+    if (den == 0.0f) return {0.0f, 0.0f};
+    return {(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+}
+PT_DEV float fresnel_complex1(float cos_i, float eta, float k) {
+    cos_i = fminf(fmaxf(cos_i, 0.0f), 1.0f);
+    Cplx ce{eta, k};
+    float sin2_i = 1.0f - cos_i * cos_i;
+    Cplx s2t = cdiv(Cplx{sin2_i, 0.0f}, cmul(ce, ce));
+    Cplx a{1.0f - s2t.re, 0.0f - s2t.im};
+    float r = sqrtf(a.re * a.re + a.im * a.im), theta = atan2f(a.im, a.re);
+    float sr = sqrtf(r), ht = theta * 0.5f;
+    Cplx ct{sr * cosf(ht), sr * sinf(ht)};
+    Cplx ec{ce.re * cos_i, ce.im * cos_i};
+    Cplx rp = cdiv(Cplx{ec.re - ct.re, ec.im - ct.im}, Cplx{ec.re + ct.re, ec.im + ct.im});
+    Cplx et = cmul(ce, ct);
+    Cplx rs = cdiv(Cplx{cos_i - et.re, 0.0f - et.im}, Cplx{cos_i + et.re, 0.0f + et.im});
+    return ((rp.re * rp.re + rp.im * rp.im) + (rs.re * rs.re + rs.im * rs.im)) * 0.5f;
+}
+
 struct GsSample { f3 wi; float pdf; float dg; float p5; bool ok; bool specular; };   // f = F(p5) * dg
 // GeneralizedSchlickBsdf::sample(.., ScatterMode::R) minus the Fresnel colour (:212-251, 342-372):
 // returns wi, pdf, the colourless factor D*G/(4|cos o|) and (1-cos)^5 so the caller applies its r0.

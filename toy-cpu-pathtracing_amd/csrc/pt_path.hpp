@@ -519,6 +519,52 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 }
             }
 
+            else if ((FEAT & FEAT_METAL) && mtype == MT_METAL) {
+                // MetalMaterial::sample -> ConductorBsdf::sample (metal_material.rs:96-148, conductor.rs:257-329);
+                // eta lives in albedo[], k in cc_tint[] for the light connection below
+                nee_kind = 4;
+                DevSpectrum es = load_spectrum(&mat->eta), ks = load_spectrum(&mat->cc_tint);
+                eval_spectrum<STATS, false>(sc, es, wl, sf.uv, albedo, st);
+                eval_spectrum<STATS, false>(sc, ks, wl, sf.uv, cc_tint, st);
+                const float alpha = mat->roughness * mat->roughness;            // roughness_to_alpha :69-71
+                if (wo_nm.z != 0.0f) {
+                    f3 wi = mk3(0, 0, 1); bool okm = false;
+                    if (alpha < 1e-3f) {                                        // sample_specular :276-298
+                        wi = mk3(-wo_nm.x, -wo_nm.y, wo_nm.z);
+                        okm = true; specular = true; s_pdf = 1.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s_f[i] = fresnel_complex1(fabsf(wi.z), albedo[i], cc_tint[i]);
+                    } else {                                                    // sample_microfacet_reflection :300-329
+                        f3 wm = ggx_sample_wm(alpha, alpha, wo_nm, uv);
+                        float wodm = dot(wo_nm, wm);
+                        wi = wm * (2.0f * wodm) - wo_nm;
+                        if (wo_nm.z * wi.z > 0.0f) {
+                            okm = true;
+                            float co = fabsf(wo_nm.z), ci = fabsf(wi.z);
+                            if (co != 0.0f && ci != 0.0f) {                         // evaluate_torrance_sparrow :331-354
+                                const float dd = ggx_D(alpha, alpha, wm), gg = ggx_G(alpha, alpha, wo_nm, wi);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) s_f[i] = fresnel_complex1(fabsf(wodm), albedo[i], cc_tint[i]) * dd * gg / (4.0f * co);
+                            }
+                            // pdf_microfacet recomputes the half vector from (wo, wi) (:414-439)
+                            f3 h = wo_nm + wi;
+                            s_pdf = 0.0f;
+                            if (dot(h, h) != 0.0f) {
+                                f3 hm = normalize(h);
+                                float jac = 4.0f * fabsf(dot(wo_nm, hm));
+                                if (jac != 0.0f) s_pdf = ggx_Dw(alpha, alpha, wo_nm, hm) / jac;
+                            }
+                        }
+                    }
+                    if (okm) {
+                        f3 w = to_world(nf, wi);
+                        float gwi = dot(ng_t, w);
+                        if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) { sampled = true; wi_sh = w; }
+                        else specular = false;
+                    }
+                }
+            }
+
             // a specular sample skips the light connection (base_renderer.rs:218); failed samples are 'Diffuse' and do not
             if (specular) nee_kind = 0;
             if (STATS) tsb = __builtin_amdgcn_s_memtime();
@@ -640,6 +686,20 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                             eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, col, st);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) fl[i] = fl[i] * col[i];
+                        }
+                    } else if ((FEAT & FEAT_METAL) && nee_kind == 4u) {          // MetalMaterial::{evaluate,pdf} (metal_material.rs:150-229)
+                        const float alpha = mat->roughness * mat->roughness;
+                        if (sgn1(gwi) == sgn1(geo_wo) && !(alpha < 1e-3f) && fabsf(wo_nm.z) != 0.0f && fabsf(wi_nm.z) != 0.0f && wo_nm.z * wi_nm.z > 0.0f) {
+                            f3 h = wo_nm + wi_nm;
+                            if (dot(h, h) != 0.0f) {
+                                f3 wm = normalize(h);
+                                float wodm = dot(wo_nm, wm);
+                                const float dd = ggx_D(alpha, alpha, wm), gg = ggx_G(alpha, alpha, wo_nm, wi_nm);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) fl[i] = fresnel_complex1(fabsf(wodm), albedo[i], cc_tint[i]) * dd * gg / (4.0f * fabsf(wo_nm.z));
+                                float jac = 4.0f * fabsf(wodm);
+                                if (jac != 0.0f) pdf_b = ggx_Dw(alpha, alpha, wo_nm, wm) / jac;
+                            }
                         }
                     } else if (!(FEAT & FEAT_CC) || nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
                         if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(HERE, "csrc", "libmi355
 
 NONE = 0xFFFFFFFF
 SPEC_CONSTANT, SPEC_RGB_ALBEDO_SRGB, SPEC_LUT470, SPEC_TEXTURE_ALBEDO_SRGB, SPEC_SIGMOID = 0, 1, 2, 3, 4
-MAT_LAMBERT, MAT_EMISSIVE, MAT_GLASS, MAT_PLASTIC, MAT_CLEARCOAT = 0, 1, 2, 3, 4
+MAT_LAMBERT, MAT_EMISSIVE, MAT_GLASS, MAT_PLASTIC, MAT_CLEARCOAT, MAT_METAL, MAT_SIMPLE_PBR = 0, 1, 2, 3, 4, 5, 6
 STRATEGY = {"pt": 0, "nee": 1, "mis": 2}
 SAMPLER = {"random": 0, "sobol": 1}
 
@@ -48,7 +48,7 @@ class MaterialDesc(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color", Spectrum), ("normal_tex", C.c_uint32), ("normal_flip_y", C.c_uint32),
                 ("intensity", C.c_float), ("eta", Spectrum), ("thin", C.c_uint32), ("roughness", C.c_float),
                 ("metallic", C.c_float), ("ior", C.c_float), ("clearcoat_ior", C.c_float), ("clearcoat_roughness", C.c_float),
-                ("clearcoat_thickness", C.c_float), ("clearcoat_tint", Spectrum)]
+                ("clearcoat_thickness", C.c_float), ("clearcoat_tint", Spectrum), ("k", Spectrum)]
 
 
 class Camera(C.Structure):

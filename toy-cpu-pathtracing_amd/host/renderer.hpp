@@ -87,6 +87,11 @@ inline Spectrum load(const std::string& name) {
 inline Spectrum cie_illum_d6500() { return load("cie_illum_d6500"); }   // spectrum/src/presets.rs:310-312
 inline Spectrum glass_sf11_eta() { return load("glass_sf11_eta"); }     // :458-460
 inline Spectrum glass_bk7_eta() { return load("glass_bk7_eta"); }
+inline Spectrum au_eta() { return load("au_eta"); }  inline Spectrum au_k() { return load("au_k"); }          // metals: presets.rs
+inline Spectrum ag_eta() { return load("ag_eta"); }  inline Spectrum ag_k() { return load("ag_k"); }
+inline Spectrum cu_eta() { return load("cu_eta"); }  inline Spectrum cu_k() { return load("cu_k"); }
+inline Spectrum al_eta() { return load("al_eta"); }  inline Spectrum al_k() { return load("al_k"); }
+inline Spectrum cu_zn_eta() { return load("cu_zn_eta"); }  inline Spectrum cu_zn_k() { return load("cu_zn_k"); }
 }  // namespace presets
 
 // ------------------------------------------------------------------ textures (scene/src/texture/*.rs)
@@ -126,6 +131,7 @@ struct NormalParameter {
 struct Material {
     uint32_t type = 0; SpectrumParameter color; NormalParameter normal; float intensity = 1; Spectrum eta; bool thin = false; float roughness = 0;
     float metallic = 0, ior = 1.5f, clearcoat_ior = 1.5f, clearcoat_roughness = 0, clearcoat_thickness = 0; SpectrumParameter clearcoat_tint;
+    Spectrum k;   // metal: extinction coefficient
 };
 struct LambertMaterial { static Material create(SpectrumParameter albedo, NormalParameter n) { Material m; m.type = MI355PT_MAT_LAMBERT; m.color = std::move(albedo); m.normal = std::move(n); return m; } };
 struct EmissiveMaterial { static Material create(SpectrumParameter radiance, FloatParameter intensity) { Material m; m.type = MI355PT_MAT_EMISSIVE; m.color = std::move(radiance); m.intensity = intensity.v; return m; } };
@@ -139,6 +145,27 @@ struct GlassMaterial {
 struct PlasticMaterial {
     static Material create(float eta, SpectrumParameter color, NormalParameter n, bool thin, FloatParameter rough) {
         Material m; m.type = MI355PT_MAT_PLASTIC; m.eta = ConstantSpectrum::create(eta); m.color = std::move(color); m.normal = std::move(n); m.thin = thin; m.roughness = rough.v; return m;
+    }
+};
+enum class MetalType { Gold, Silver, Copper, Aluminum, Brass };                       // metal_material.rs:16-29
+struct MetalMaterial {                                                                 // metal_material.rs:44-92
+    static Material create(MetalType t, NormalParameter n, FloatParameter rough) {
+        Material m; m.type = MI355PT_MAT_METAL; m.normal = std::move(n); m.roughness = rough.v;
+        m.color = SpectrumParameter::constant(ConstantSpectrum::create(1.0f));
+        switch (t) {
+            case MetalType::Gold: m.eta = presets::au_eta(); m.k = presets::au_k(); break;
+            case MetalType::Silver: m.eta = presets::ag_eta(); m.k = presets::ag_k(); break;
+            case MetalType::Copper: m.eta = presets::cu_eta(); m.k = presets::cu_k(); break;
+            case MetalType::Aluminum: m.eta = presets::al_eta(); m.k = presets::al_k(); break;
+            case MetalType::Brass: m.eta = presets::cu_zn_eta(); m.k = presets::cu_zn_k(); break;
+        }
+        return m;
+    }
+};
+struct SimplePbrMaterial {                                                             // simple_pbr_material.rs:29-45
+    static Material create(SpectrumParameter base_color, FloatParameter metallic, FloatParameter roughness, NormalParameter n, FloatParameter ior) {
+        Material m; m.type = MI355PT_MAT_SIMPLE_PBR; m.color = std::move(base_color); m.metallic = metallic.v; m.roughness = roughness.v;
+        m.normal = std::move(n); m.ior = ior.v; return m;
     }
 };
 struct SimpleClearcoatPbrMaterial {
@@ -169,6 +196,7 @@ struct Transform {
         r.m[0] = 1.0f - yy; r.m[2] = -wy; r.m[8] = wy; r.m[10] = 1.0f - yy;
         return mul(r, *this);
     }
+    static Transform from_scale(Vec3 v) { Transform s = identity(); s.m[0] = v.x; s.m[5] = v.y; s.m[10] = v.z; return s; }   // :119-122
     Transform scale(Vec3 v) const { Transform s = identity(); s.m[0] = v.x; s.m[5] = v.y; s.m[10] = v.z; return mul(s, *this); }
     Transform translate(Vec3 v) const { Transform t = identity(); t.m[12] = v.x; t.m[13] = v.y; t.m[14] = v.z; return mul(t, *this); }
 };
@@ -291,7 +319,8 @@ public:
         md.type = m.type; md.color = lower(m.color); md.normal_tex = MI355PT_NONE;
         if (m.normal.has) { md.normal_tex = add_tex(*m.normal.tex.img); md.normal_flip_y = m.normal.tex.flip_y ? 1 : 0; }
         md.intensity = m.intensity; md.thin = m.thin ? 1 : 0; md.roughness = m.roughness;
-        if (m.type == MI355PT_MAT_GLASS || m.type == MI355PT_MAT_PLASTIC) md.eta = lower_spectrum(m.eta);
+        if (m.type == MI355PT_MAT_GLASS || m.type == MI355PT_MAT_PLASTIC || m.type == MI355PT_MAT_METAL) md.eta = lower_spectrum(m.eta);
+        if (m.type == MI355PT_MAT_METAL) md.k = lower_spectrum(m.k);
         md.metallic = m.metallic; md.ior = m.ior; md.clearcoat_ior = m.clearcoat_ior; md.clearcoat_roughness = m.clearcoat_roughness;
         md.clearcoat_thickness = m.clearcoat_thickness;
         if (m.type == MI355PT_MAT_CLEARCOAT) md.clearcoat_tint = lower(m.clearcoat_tint);

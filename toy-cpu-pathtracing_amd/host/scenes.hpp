@@ -1,4 +1,4 @@
-// load_scene_N(&mut scene, &mut camera) of renderer/src/scene/scene_{3,8,10,17}.rs, call for call.
+// load_scene_N(&mut scene, &mut camera) of renderer/src/scene/scene_{0,3,6,7,8,10,11,17}.rs, call for call.
 // Asset paths keep the reference's names under $MI355PT_ASSETS (default ./assets); the files are the synthetic
 // stand-ins written by tools/export_assets.py (the reference's are git-LFS stubs), textures as binary PPM.
 #pragma once
@@ -36,6 +36,37 @@ inline void load_scene_3(Scene& scene, Camera& camera) {            // scene_3.r
     scene.create_primitive(GeometryPrimitive{geom, LambertMaterial::create(spectrum_param, normal_param), Transform::identity()});
     load_room(scene);
     camera.set_look_to({0.0f, 3.15221f, 6.0f}, {0.0f, -0.9f, -3.2f}, {0.0f, 1.0f, 0.0f});
+}
+inline void load_scene_0(Scene& scene, Camera& camera) {            // scene_0.rs: constant grey Lambert hero
+    GeometryIndex geom = scene.load_obj(asset("bunny.obj"));
+    scene.create_primitive(GeometryPrimitive{geom, LambertMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.8f, 0.8f, 0.8f})), NormalParameter::none()),
+                                             Transform::identity()});
+    load_room(scene);
+    camera.set_look_to({0.0f, 3.15221f, 6.0f}, {0.0f, -0.9f, -3.2f}, {0.0f, 1.0f, 0.0f});
+}
+inline void load_scene_6(Scene& scene, Camera& camera) {            // scene_6.rs:13-110: smooth gold hero
+    GeometryIndex geom = scene.load_obj(asset("bunny.obj"));
+    scene.create_primitive(GeometryPrimitive{geom, MetalMaterial::create(MetalType::Gold, NormalParameter::none(), FloatParameter::constant(0.0f)), Transform::identity()});
+    load_room(scene);
+    camera.set_look_to({0.0f, 3.5f, 6.0f}, {0.0f, -1.0f, -3.0f}, {0.0f, 1.0f, 0.0f});
+}
+inline void load_scene_7(Scene& scene, Camera& camera) {            // scene_7.rs:13-130: four gold heroes, roughness 0.05 .. 0.75
+    GeometryIndex bunny_geom = scene.load_obj(asset("bunny.obj"));
+    const float scale = 0.6f;
+    const Vec3 positions[4] = {{-1.3f, 0.0f, -0.5f}, {-0.5f, 0.0f, -0.5f}, {0.3f, 0.0f, -0.5f}, {1.1f, 0.0f, -0.5f}};
+    const float roughness_values[4] = {0.05f, 0.25f, 0.5f, 0.75f};
+    for (int i = 0; i < 4; ++i)
+        scene.create_primitive(GeometryPrimitive{bunny_geom, MetalMaterial::create(MetalType::Gold, NormalParameter::none(), FloatParameter::constant(roughness_values[i])),
+                                                 Transform::from_scale({scale, scale, scale}).translate(positions[i])});
+    load_room(scene);
+    camera.set_look_to({0.0f, 2.5f, 5.0f}, {0.0f, -0.7f, -2.5f}, {0.0f, 1.0f, 0.0f});
+}
+inline void load_scene_11(Scene& scene, Camera& camera) {           // scene_11.rs: SF11 glass hero with roughness 0.2
+    GeometryIndex geom = scene.load_obj(asset("bunny.obj"));
+    scene.create_primitive(GeometryPrimitive{geom, GlassMaterial::create(GlassType::Sf11, NormalParameter::none(), false, FloatParameter::constant(0.2f)),
+                                             Transform::identity()});
+    load_room(scene);
+    camera.set_look_to({0.0f, 3.5f, 6.0f}, {0.0f, -1.0f, -3.0f}, {0.0f, 1.0f, 0.0f});
 }
 inline void load_scene_8(Scene& scene, Camera& camera) {            // scene_8.rs:13-111
     GeometryIndex geom = scene.load_obj(asset("bunny.obj"));

@@ -8,8 +8,8 @@ import subprocess
 import numpy as np
 
 from . import assets
-from .ffi import (HERE, MAT_CLEARCOAT, MAT_EMISSIVE, MAT_GLASS, MAT_LAMBERT, MAT_PLASTIC, NONE, MaterialDesc, Spectrum,
-                  make_camera)
+from .ffi import (HERE, MAT_CLEARCOAT, MAT_EMISSIVE, MAT_GLASS, MAT_LAMBERT, MAT_METAL, MAT_PLASTIC, MAT_SIMPLE_PBR, NONE, MaterialDesc,
+                  Spectrum, make_camera)
 
 DATA = os.path.join(HERE, "data")
 
@@ -125,6 +125,32 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         scene.add_instance(g, scene.add_material(d))
         _room(scene, p)
         cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id in (6, 7):     # scene_6.rs:16-26: smooth gold hero; scene_7.rs:16-39: four gold heroes, roughness 0.05..0.75
+        g = scene.add_mesh(_asset("bunny"))
+        lut_eta, lut_k = scene.add_lut470(p["au_eta"]), scene.add_lut470(p["au_k"])
+
+        def gold(roughness):
+            d = MaterialDesc(); d.type = MAT_METAL; d.eta = Spectrum.lut(lut_eta); d.k = Spectrum.lut(lut_k)
+            d.normal_tex = NONE; d.roughness = roughness; d.color = Spectrum.constant(1.0)
+            return d
+        if scene_id == 6:
+            scene.add_instance(g, scene.add_material(gold(0.0)))
+            _room(scene, p)
+            cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+        else:
+            for pos, rough in zip([(-1.3, 0.0, -0.5), (-0.5, 0.0, -0.5), (0.3, 0.0, -0.5), (1.1, 0.0, -0.5)], [0.05, 0.25, 0.5, 0.75]):
+                # Transform::from_scale(0.6).translate(position) = T * S (transform.rs:119-129)
+                m = np.diag(np.array([0.6, 0.6, 0.6, 1.0], dtype=np.float32)); m[:3, 3] = np.array(pos, dtype=np.float32)
+                scene.add_instance(g, scene.add_material(gold(rough)), m)
+            _room(scene, p)
+            cam = make_camera((0.0, 2.5, 5.0), (0.0, -0.7, -2.5), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 20:   # not a reference scene: scene 17's hero with SimplePbrMaterial (mixed metallic) — exercises simple_pbr_material.rs
+        g = scene.add_mesh(_asset("dragon"))
+        d = MaterialDesc(); d.type = MAT_SIMPLE_PBR; d.color = Spectrum.rgb_albedo_srgb(0.8, 0.5, 0.3)
+        d.metallic = 0.4; d.roughness = 0.5; d.normal_tex = NONE; d.ior = 1.5
+        scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
+        _room(scene, p)
+        cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
     elif scene_id == 17:   # scene_17.rs:20-70: rough clearcoat over rough metal
         g = scene.add_mesh(_asset("dragon"))
         d = MaterialDesc(); d.type = MAT_CLEARCOAT; d.color = Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8)
