@@ -77,6 +77,18 @@ typedef struct mi355pt_material_desc {
     mi355pt_spectrum k;     /* metal only: extinction coefficient */
 } mi355pt_material_desc;
 
+/* ---- delta lights: CreatePrimitiveDesc::{PointLightPrimitive, SpotLightPrimitive, DirectionalLightPrimitive}
+ *      (scene/src/primitive/create_desc.rs:35-66; primitive/impls/{point,spot,directional}_light.rs).  The spot light
+ *      looks down its local +z, the directional light shines along its local +z. ---- */
+enum { MI355PT_LIGHT_POINT = 1, MI355PT_LIGHT_SPOT = 2, MI355PT_LIGHT_DIRECTIONAL = 3 };
+typedef struct mi355pt_light_desc {
+    uint32_t kind;
+    float intensity;
+    float angle_inner, angle_outer; /* spot only; compared against the cosine exactly as spot_light.rs:110-112 does */
+    mi355pt_spectrum spectrum;      /* constant or LUT470 */
+    float local_to_world[16];       /* column-major */
+} mi355pt_light_desc;
+
 /* ---- camera: renderer::Camera::new + set_look_to (renderer/src/camera.rs:27-49) ---- */
 typedef struct mi355pt_camera {
     float position[3];  /* world space */
@@ -135,6 +147,9 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* de
 /* Scene::create_primitive(CreatePrimitiveDesc::GeometryPrimitive{geometry_index, surface_material, transform})
  * scene.rs:57-61, primitive/create_desc.rs:10-15.  Emissive materials make the instance an area light. */
 int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, const float local_to_world[16]);
+/* Scene::create_primitive(CreatePrimitiveDesc::{Point,Spot,Directional}LightPrimitive{..})  scene.rs:57-61.  Lights and
+ * emissive instances enter the light sampler in creation order (light_sampler.rs:163-180). */
+int mi355pt_scene_add_delta_light(mi355pt_scene* s, const mi355pt_light_desc* desc);
 /* Scene::build(&camera): world->render translation, BVH build, light list; uploads to the current HIP device.
  * scene.rs:64-76 */
 int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam);

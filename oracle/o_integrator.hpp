@@ -162,6 +162,43 @@ struct PathTracer {
         *contrib = f * rad.radiance * g / (rad.pdf * light_prob);
     }
 
+    // evaluate_delta_point_light / evaluate_delta_directional_light (common.rs:23-79) for PointLight, SpotLight
+    // (PrimitiveDeltaPointLight, {point,spot}_light.rs) and DirectionalLight (directional_light.rs:95-107); MIS weight 1.
+    SS eval_delta_light(const DeltaLight& d, const SurfaceInteraction& sp, const Material& mat, const Wavelengths& wl, V3 wo_render,
+                        const M4& r2t, float light_prob, Counters* c, uint64_t mc_key) const {
+        MaterialEval me{scene, c};
+        me.mc_key = mc_key;
+        ShadingPoint spt{transform_normal(r2t, sp.normal), sp.uv};
+        V3 wo = transform_vector3(r2t, wo_render);
+        if (d.kind == DL_DIRECTIONAL) {
+            V3 direction = normalize(transform_vector3(d.local_to_render, V3{0.0f, 0.0f, 1.0f}));
+            SS intensity = d.intensity * d.spectrum.sample(wl);
+            Ray shadow{sp.position, direction};                                             // not moved forward (:60-61)
+            if (scene.intersect_p(shadow, std::numeric_limits<float>::max(), c)) return SS::zero();
+            V3 wi = transform_vector3(r2t, normalize(direction));
+            SS f = me.evaluate(mat, wl, wo, wi, spt);
+            return f * intensity / light_prob;
+        }
+        V3 position = transform_point3(d.local_to_render, V3{0.0f, 0.0f, 0.0f});
+        SS intensity = d.intensity * d.spectrum.sample(wl);
+        if (d.kind == DL_SPOT) {                                                            // spot_light.rs:99-122
+            V3 wi_l = normalize(position - sp.position);
+            float a = d.angle_outer, b = d.angle_inner;
+            float theta = transform_vector3(inverse(d.local_to_render), wi_l).z;
+            float t = std::fmin(std::fmax((theta - a) / (b - a), 0.0f), 1.0f);
+            float falloff = t * t * (3.0f - 2.0f * t);
+            intensity = intensity * falloff;
+        }
+        V3 dv = position - sp.position;
+        Ray shadow = move_forward(Ray{sp.position, normalize(dv)}, SHADOW_EPS);
+        float t = length(dv) - 2.0f * SHADOW_EPS;
+        if (scene.intersect_p(shadow, t, c)) return SS::zero();
+        V3 wi = transform_vector3(r2t, normalize(dv));
+        SS f = me.evaluate(mat, wl, wo, wi, spt);
+        float distance2 = length_squared(dv);
+        return f * intensity / (distance2 * light_prob);
+    }
+
     // one camera path; returns L and the (possibly terminated) wavelengths
     SS trace(uint32_t px, uint32_t py, uint32_t sample_index, Wavelengths* wl_out, Counters* c) const {
         Sampler smp = Sampler::create((int)prm.sampler, prm.spp, prm.width, prm.height, prm.seed);
@@ -197,10 +234,15 @@ struct PathTracer {
                 if (ls.sample_light(ul, &lprim, &lprob)) {
                     float s = smp.get_1d();
                     V2 luv = smp.get_2d();
-                    AreaSample as = sample_area_light(lprim, hit.interaction.position, wl, s, luv, c);
-                    SS contrib; float w;
-                    eval_area_light(hit.interaction, as, mat, wl, hit.wo, r2t, lprob, prm.strategy == STRAT_MIS, &contrib, &w, c, me.mc_key);
-                    L = L + (T * contrib) * w;
+                    if (lprim < 0) {                                                        // Scene::calculate_light (scene.rs:114-139)
+                        SS contrib = eval_delta_light(scene.delta_lights[-1 - lprim], hit.interaction, mat, wl, hit.wo, r2t, lprob, c, me.mc_key);
+                        L = L + (T * contrib) * 1.0f;
+                    } else {
+                        AreaSample as = sample_area_light(lprim, hit.interaction.position, wl, s, luv, c);
+                        SS contrib; float w;
+                        eval_area_light(hit.interaction, as, mat, wl, hit.wo, r2t, lprob, prm.strategy == STRAT_MIS, &contrib, &w, c, me.mc_key);
+                        L = L + (T * contrib) * w;
+                    }
                 }
             }
             // process_bsdf_sampling (base_renderer.rs:95-139)

@@ -7,7 +7,7 @@
 
 namespace oracle {
 
-constexpr float PI_F = 3.14159265358979323846f;
+
 
 enum BsdfSampleType : uint32_t { ST_DIFFUSE = 0, ST_SPEC_REFL = 1, ST_SPEC_TRANS = 2, ST_GLOSSY_REFL = 3, ST_GLOSSY_TRANS = 4 };
 

@@ -13,6 +13,7 @@
 #include <limits>
 
 namespace oracle {
+constexpr float PI_F = 3.14159265358979323846f;
 
 struct V2 { float x, y; };
 

@@ -2,6 +2,7 @@
 // Restatement of scene/src/{scene,samples,light_sampler}.rs, scene/src/primitive/{bvh,impls/
 // triangle_mesh,impls/emissive_triangle_mesh}.rs and scene/src/geometry/impls/triangle_mesh.rs.
 #pragma once
+#include <algorithm>
 #include <memory>
 #include <vector>
 #include "o_bvh.hpp"
@@ -102,8 +103,20 @@ struct Primitive {
     M4 local_to_render = M4::identity();
     M4 render_to_local = M4::identity();   // used only by fast mode (hoisted inverse)
     bool is_light = false;
+    uint32_t seq = 0;                      // creation order among all primitives
     std::vector<float> area_list, area_table;
     float area_sum = 0.0f;
+};
+
+// PointLight / SpotLight / DirectionalLight primitives (primitive/impls/{point,spot,directional}_light.rs)
+enum DeltaKind : uint32_t { DL_POINT = 1, DL_SPOT = 2, DL_DIRECTIONAL = 3 };
+struct DeltaLight {
+    uint32_t kind = DL_POINT;
+    float intensity = 1.0f, angle_inner = 0.0f, angle_outer = 0.0f;
+    Spectrum spectrum;
+    M4 local_to_world = M4::identity(), local_to_render = M4::identity();
+    float area = 0.0f;            // DirectionalLight::preprocess (directional_light.rs:46-54)
+    uint32_t seq = 0;             // creation order among all primitives (light_list order, light_sampler.rs:163-180)
 };
 
 struct Counters {
@@ -126,7 +139,9 @@ struct Scene {
     std::vector<std::unique_ptr<TriangleMesh>> geometries;
     std::vector<Material> materials;
     std::vector<Primitive> primitives;
-    std::vector<int> light_list;                  // LightSamplerFactory::light_list
+    std::vector<DeltaLight> delta_lights;
+    uint32_t next_seq = 0;
+    std::vector<int> light_list;                  // LightSamplerFactory::light_list: >= 0 primitive index, < 0 delta light -1-k
     Bvh tlas;
     bool faithful = true;                         // see o_bvh.hpp
     bool built = false;
@@ -152,17 +167,34 @@ struct Scene {
     void build(V3 cam_pos) {
         M4 world_to_render = M4::from_translation(-cam_pos);     // camera.rs:84-86
         light_list.clear();
+        std::vector<std::pair<uint32_t, int>> order;     // (creation sequence, light_list entry)
         for (size_t i = 0; i < primitives.size(); ++i) {
             Primitive& p = primitives[i];
             p.local_to_render = world_to_render * p.local_to_world;
             p.render_to_local = inverse(p.local_to_render);
             p.is_light = materials[p.material].is_emissive();
-            if (p.is_light) { init_light(p); light_list.push_back((int)i); }
+            if (p.is_light) { init_light(p); order.push_back({p.seq, (int)i}); }
         }
         for (auto& g : geometries) if (g->bvh.nodes.empty()) g->build();
         tlas = Bvh::build((uint32_t)primitives.size(), [this](uint32_t i) {
             return transform_bounds(primitives[i].local_to_render, geometries[primitives[i].geometry]->bounds);
         });
+        // scene bounds for DirectionalLight::preprocess: union of the primitives' render-space bounds (scene.rs:70-73)
+        Bounds sb = transform_bounds(primitives[0].local_to_render, geometries[primitives[0].geometry]->bounds);
+        for (size_t i = 1; i < primitives.size(); ++i) {
+            Bounds b = transform_bounds(primitives[i].local_to_render, geometries[primitives[i].geometry]->bounds);
+            sb.mn = vmin(sb.mn, b.mn); sb.mx = vmax(sb.mx, b.mx);
+        }
+        V3 center = (sb.mn + sb.mx) * 0.5f;                       // bounds.rs:59-77
+        float radius = length(center - sb.mx);
+        for (size_t k = 0; k < delta_lights.size(); ++k) {
+            DeltaLight& d = delta_lights[k];
+            d.local_to_render = world_to_render * d.local_to_world;
+            d.area = PI_F * radius * radius;
+            order.push_back({d.seq, -1 - (int)k});
+        }
+        std::sort(order.begin(), order.end());
+        for (auto& o : order) light_list.push_back(o.second);
         built = true;
     }
 
@@ -223,6 +255,15 @@ struct Scene {
     // ---- lights ----
     // EmissiveMaterial::average_intensity * area_sum (emissive_material.rs:63-79, emissive_triangle_mesh.rs:166-173)
     SS light_phi(int prim, const Wavelengths& w) const {
+        if (prim < 0) {
+            const DeltaLight& d = delta_lights[-1 - prim];
+            SS s = d.spectrum.sample(w);
+            if (d.kind == DL_POINT) return (4.0f * PI_F * d.intensity) * s;                        // point_light.rs:78-81
+            if (d.kind == DL_SPOT)                                                                  // spot_light.rs:84-96
+                return ((d.intensity * s) * 2.0f * PI_F) *
+                       ((1.0f - std::cos(d.angle_inner)) + (std::cos(d.angle_inner) - std::cos(d.angle_outer)) / 2.0f);
+            return (d.intensity * d.area) * s;                                                      // directional_light.rs:40-44
+        }
         const Primitive& p = primitives[prim];
         const Material& m = materials[p.material];
         SS rad = sample_spectrum_param(m.color, V2{0.5f, 0.5f}, w, nullptr);

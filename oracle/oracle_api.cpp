@@ -114,7 +114,17 @@ int ptoracle_scene_add_material(ptoracle_scene* s, const mi355pt_material_desc* 
 int ptoracle_scene_add_instance(ptoracle_scene* s, uint32_t geom, uint32_t mat, const float* l2w) {
     if (geom >= s->scene.geometries.size() || mat >= s->scene.materials.size()) return -1;
     Primitive p; p.geometry = (int)geom; p.material = (int)mat; p.local_to_world = M4::from_cols16(l2w);
+    p.seq = s->scene.next_seq++;
     s->scene.primitives.push_back(p);
+    return 0;
+}
+int ptoracle_scene_add_delta_light(ptoracle_scene* s, const mi355pt_light_desc* d) {
+    if (d->kind < MI355PT_LIGHT_POINT || d->kind > MI355PT_LIGHT_DIRECTIONAL) return -1;
+    DeltaLight l; l.kind = d->kind; l.intensity = d->intensity; l.angle_inner = d->angle_inner; l.angle_outer = d->angle_outer;
+    if (!lower_spectrum(s, d->spectrum, &l.spectrum)) return -1;
+    l.local_to_world = M4::from_cols16(d->local_to_world);
+    l.seq = s->scene.next_seq++;
+    s->scene.delta_lights.push_back(l);
     return 0;
 }
 int ptoracle_scene_build(ptoracle_scene* s, const mi355pt_camera* cam) {

@@ -154,6 +154,14 @@ def dragon_class():
     return blob_mesh(128, 81, seed=23, lobes=(14, 0.30, 8.0, 60, 0.05, 60.0), center=(0.0, 0.5, 0.0), scale=0.42)
 
 
+def single_triangle():
+    """The SingleTrianglePrimitive of scene_1.rs:46-67 as a one-triangle mesh (positions, +z normals, uvs)."""
+    pos = np.array([[-2.0, 0.0, 0.0], [2.0, 0.0, 0.0], [-2.0, 4.0, 0.0]], dtype=F)
+    nrm = np.array([[0, 0, 1]] * 3, dtype=F)
+    uv = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]], dtype=F)
+    return dict(pos=pos, nrm=nrm, uv=uv, idx=np.array([[0, 1, 2]], dtype=np.uint32))
+
+
 def _value_noise(n, octaves, rng):
     out = np.zeros((n, n))
     amp, tot = 1.0, 0.0

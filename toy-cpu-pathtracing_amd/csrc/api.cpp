@@ -262,6 +262,22 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
     *out = (uint32_t)im.materials.size() - 1;
     return MI355PT_OK;
 }
+int mi355pt_scene_add_delta_light(mi355pt_scene* s, const mi355pt_light_desc* d) {
+    if (!s || !d) return fail(MI355PT_E_INVALID, "null argument");
+    if (d->kind < MI355PT_LIGHT_POINT || d->kind > MI355PT_LIGHT_DIRECTIONAL) return fail(MI355PT_E_INVALID, "bad light kind");
+    SceneImpl& im = s->impl;
+    DevMaterial m{};                        // hidden emissive material: carries the light's spectrum with intensity 1
+    std::string err;
+    int rc;
+    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.intensity = 1.0f;
+    if ((rc = im.lower_spectrum(d->spectrum, &m.color, false, &err))) return fail(rc, "light spectrum: " + err);
+    im.materials.push_back(m);
+    mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.color = d->spectrum; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE;
+    im.mat_descs.push_back(md);
+    HostDeltaLight hl{*d, (uint32_t)im.materials.size() - 1, (uint32_t)im.instances.size()};
+    im.delta_lights.push_back(hl);
+    return MI355PT_OK;
+}
 int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, const float* l2w) {
     if (!s || !l2w) return fail(MI355PT_E_INVALID, "null argument");
     if (geom >= s->impl.meshes.size() || mat >= s->impl.materials.size()) return fail(MI355PT_E_INVALID, "bad geometry/material id");

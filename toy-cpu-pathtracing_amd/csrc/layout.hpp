@@ -101,11 +101,21 @@ struct alignas(16) DevLightTri {
 };
 static_assert(sizeof(DevLightTri) == 48, "light tri");
 
-struct DevLight {
-    uint32_t first_tri, n_tris;   // into light_tris
-    uint32_t material;
-    float area_sum;
+enum : uint32_t { LK_AREA = 0, LK_POINT = 1, LK_SPOT = 2, LK_DIRECTIONAL = 3 };
+struct alignas(16) DevLight {
+    uint32_t first_tri, n_tris;   // area: into light_tris
+    uint32_t material;            // emissive material (delta lights: a hidden one holding the spectrum, intensity 1)
+    float area_sum;               // area: sum of triangle areas; delta: the scalar factor of phi (4 pi I, ...), so that
+                                  // the light-pick weight is mean_lambda((spectrum * material.intensity) * area_sum) for every kind
+    uint32_t kind;                // LK_*
+    float intensity;              // delta lights
+    float angle_inner, angle_outer;   // spot
+    float pos[3];                 // point/spot: render-space position; directional: normalised render-space direction
+    float pad0;
+    float axis[3];                // spot: third row of the linear part of render_to_local ((inv * w).z = dot(axis, w))
+    float pad1;
 };
+static_assert(sizeof(DevLight) == 64, "light record");
 
 struct DevTexture {
     uint32_t offset;   // texel offset into the RGBA8 pool
@@ -151,7 +161,7 @@ struct DevParams {
 
 // Scene feature bits: the host picks the smallest kernel specialisation that covers the scene's materials, so a
 // Lambert-only Cornell box does not carry the registers and code of the clearcoat / dielectric / texture paths.
-enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_METAL = 32, FEAT_ALL = 63 };
+enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_METAL = 32, FEAT_DELTA = 64, FEAT_ALL = 127 };
 
 struct DevStats {
     unsigned long long samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;

@@ -622,8 +622,27 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     float lprob = wpick / wsum;
                     float s1 = get_1d(smp, sctx);
                     f2 luv = get_2d(smp, sctx);
-                    // EmissiveTriangleMesh::sample_radiance (emissive_triangle_mesh.rs:176-308)
                     DevLight lt = sc.lights[pick];
+                    const DevMaterial* lm = sc.materials + lt.material;
+                    f3 dv, wi_r, ln = mk3(0, 0, 1);
+                    float pdf_a = 1.0f, pdf_dir = 0.0f;
+                    float dl_scale = 1.0f;                                      // delta lights: falloff
+                    if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
+                        // Scene::calculate_light for PrimitiveDelta{Point,Directional}Light (scene.rs:114-139)
+                        if (lt.kind == LK_DIRECTIONAL) {                        // directional_light.rs:95-107
+                            dv = mk3(lt.pos[0], lt.pos[1], lt.pos[2]);
+                            wi_r = normalize(dv);
+                        } else {                                                // point_light.rs:83-93, spot_light.rs:99-122
+                            dv = mk3(lt.pos[0], lt.pos[1], lt.pos[2]) - sf.p;
+                            wi_r = normalize(dv);
+                            if (lt.kind == LK_SPOT) {
+                                float theta = lt.axis[0] * wi_r.x + lt.axis[1] * wi_r.y + lt.axis[2] * wi_r.z;
+                                float t = fminf(fmaxf((theta - lt.angle_outer) / (lt.angle_inner - lt.angle_outer), 0.0f), 1.0f);
+                                dl_scale = t * t * (3.0f - 2.0f * t);
+                            }
+                        }
+                    } else {
+                    // EmissiveTriangleMesh::sample_radiance (emissive_triangle_mesh.rs:176-308)
                     // first k with s < cdf[k] (else 0, :185-191).  The cdf is non-decreasing, so that index is the
                     // number of entries <= s: independent loads instead of a chain of dependent ones.
                     uint32_t cnt = 0;
@@ -636,13 +655,13 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
                     float b2 = 1.0f - b0 - b1;
                     f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
-                    f3 ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
-                    const DevMaterial* lm = sc.materials + lt.material;
-                    float pdf_a = 1.0f / lt.area_sum;
-                    f3 dv = lp - sf.p;
-                    f3 wi_r = normalize(dv);
+                    ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
+                    pdf_a = 1.0f / lt.area_sum;
+                    dv = lp - sf.p;
+                    wi_r = normalize(dv);
                     float distance = length(lp - sf.p);
-                    float pdf_dir = pdf_a * (distance * distance) / fmaxf(fabsf(dot(ln, -wi_r)), 1e-8f);
+                    pdf_dir = pdf_a * (distance * distance) / fmaxf(fabsf(dot(ln, -wi_r)), 1e-8f);
+                    }
                     // evaluate_area_light{,_with_mis} (common.rs:82-171)
                     f3 wi_t = to_local(fr, wi_r);
                     f3 wi_nm = to_local(nf, wi_t);
@@ -733,14 +752,31 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         pdf_b = thick <= 0.0f ? pdf_base : pdfc * cc_fc + pdf_base * (1.0f - cc_fc);
                     }
                     float dist2 = dot(dv, dv);
+                    do_shadow = true;
+                    if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
+                        // evaluate_delta_{point,directional}_light (common.rs:23-79): no MIS weight
+                        if (lt.kind == LK_DIRECTIONAL) {
+                            sh_d = dv; sh_o = sf.p; sh_t = 3.402823466e+38f;      // the ray is not moved forward (:60-61)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sh_c[i] = (T[i] * ((fl[i] * (lt.intensity * lrad[i])) / lprob)) * 1.0f;
+                        } else {
+                            sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                float inten = lt.intensity * lrad[i];
+                                if (lt.kind == LK_SPOT) inten = inten * dl_scale;
+                                sh_c[i] = (T[i] * ((fl[i] * inten) / (dist2 * lprob))) * 1.0f;
+                            }
+                        }
+                    } else {
                     f3 ln_t = normalize(to_local(fr, ln));
                     float g = fabsf(dot(ln_t, -wi_t)) / dist2;
                     float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
-                    do_shadow = true;
                     sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         sh_c[i] = (T[i] * ((fl[i] * (lrad[i] * lm->intensity)) * g / (pdf_a * lprob))) * wgt;
+                    }
                 }
             }
 

@@ -136,12 +136,51 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     std::vector<DevLight> lights;
     std::vector<DevLightTri> light_tris;
 
+    // delta lights enter the light list in creation order, interleaved with the emissive instances
+    size_t next_delta = 0;
+    float sb_lo[3] = {INFINITY, INFINITY, INFINITY}, sb_hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // scene bounds (render space)
+    auto push_delta = [&](const HostDeltaLight& hl) {
+        DevLight dl{};
+        dl.first_tri = 0; dl.n_tris = 0; dl.material = hl.material; dl.kind = hl.d.kind;   // LK_* == MI355PT_LIGHT_*
+        dl.intensity = hl.d.intensity; dl.angle_inner = hl.d.angle_inner; dl.angle_outer = hl.d.angle_outer;
+        float l2r[16];
+        mat4_mul(w2r, hl.d.local_to_world, l2r);
+        if (hl.d.kind == MI355PT_LIGHT_DIRECTIONAL) {
+            V3 d = normalize(V3{l2r[8], l2r[9], l2r[10]});                        // local_to_render * (0,0,1), normalised
+            dl.pos[0] = d.x; dl.pos[1] = d.y; dl.pos[2] = d.z;
+        } else {
+            dl.pos[0] = l2r[12]; dl.pos[1] = l2r[13]; dl.pos[2] = l2r[14];       // local_to_render * Point3::ZERO
+            double a[9] = {l2r[0], l2r[1], l2r[2], l2r[4], l2r[5], l2r[6], l2r[8], l2r[9], l2r[10]};   // column-major linear part
+            double det = a[0] * (a[4] * a[8] - a[7] * a[5]) - a[3] * (a[1] * a[8] - a[7] * a[2]) + a[6] * (a[1] * a[5] - a[4] * a[2]);
+            // third row of the inverse: (inv * w).z (spot_light.rs:110)
+            dl.axis[0] = (float)((a[1] * a[5] - a[4] * a[2]) / det);
+            dl.axis[1] = (float)(-(a[0] * a[5] - a[3] * a[2]) / det);
+            dl.axis[2] = (float)((a[0] * a[4] - a[3] * a[1]) / det);
+        }
+        // phi's scalar factor ({point,spot,directional}_light.rs: phi()); the directional area is filled once the bounds are known
+        const float PI_F = 3.14159265358979323846f;
+        if (hl.d.kind == MI355PT_LIGHT_POINT) dl.area_sum = 4.0f * PI_F * hl.d.intensity;
+        else if (hl.d.kind == MI355PT_LIGHT_SPOT)   // ((I*s)*2*pi)*bracket in the reference; here s*(I*2*pi*bracket): same value up to rounding
+            dl.area_sum = hl.d.intensity * 2.0f * PI_F * ((1.0f - std::cos(hl.d.angle_inner)) + (std::cos(hl.d.angle_inner) - std::cos(hl.d.angle_outer)) / 2.0f);
+        lights.push_back(dl);
+    };
+
     for (size_t ii = 0; ii < instances.size(); ++ii) {
+        while (next_delta < delta_lights.size() && delta_lights[next_delta].after_instances <= ii) push_delta(delta_lights[next_delta++]);
         const HostInstance& inst = instances[ii];
         const HostMesh& mesh = meshes[inst.geom];
         const DevMaterial& mat = materials[inst.mat];
         float l2r[16];
         mat4_mul(w2r, inst.l2w, l2r);                                          // triangle_mesh.rs:38-40
+        {   // primitive bounds = the mesh's local AABB carried through local_to_render (primitive/impls/triangle_mesh.rs:62-70)
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t v = 0; v < mesh.n_vert; ++v) for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], mesh.pos[3 * v + a]); hi[a] = std::fmax(hi[a], mesh.pos[3 * v + a]); }
+            for (int k = 0; k < 8; ++k) {
+                V3 q = xform_point(l2r, V3{(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]});
+                sb_lo[0] = std::fmin(sb_lo[0], q.x); sb_lo[1] = std::fmin(sb_lo[1], q.y); sb_lo[2] = std::fmin(sb_lo[2], q.z);
+                sb_hi[0] = std::fmax(sb_hi[0], q.x); sb_hi[1] = std::fmax(sb_hi[1], q.y); sb_hi[2] = std::fmax(sb_hi[2], q.z);
+            }
+        }
         DevInstance& di = dinst[ii];
         di.lin[0] = l2r[0]; di.lin[1] = l2r[1]; di.lin[2] = l2r[2];
         di.lin[3] = l2r[4]; di.lin[4] = l2r[5]; di.lin[5] = l2r[6];
@@ -166,7 +205,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             for (float a : area_list) { area_sum += a; area_table.push_back(area_sum); }
             for (float& a : area_table) a /= area_sum;
             light_index = (uint32_t)lights.size();
-            lights.push_back(DevLight{(uint32_t)light_tris.size(), mesh.n_tri, inst.mat, area_sum});
+            { DevLight al{}; al.first_tri = (uint32_t)light_tris.size(); al.n_tris = mesh.n_tri; al.material = inst.mat; al.area_sum = area_sum; al.kind = LK_AREA;
+              lights.push_back(al); }
         }
         for (uint32_t t = 0; t < mesh.n_tri; ++t) {
             V3 p[3];
@@ -212,6 +252,15 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
                 light_tris.push_back(lt);
             }
             shade_unordered.push_back(sh);
+        }
+    }
+    while (next_delta < delta_lights.size()) push_delta(delta_lights[next_delta++]);
+    {   // DirectionalLight::preprocess (directional_light.rs:46-54): area = pi r^2 of the scene's bounding sphere (bounds.rs:59-77)
+        V3 c{(sb_lo[0] + sb_hi[0]) * 0.5f, (sb_lo[1] + sb_hi[1]) * 0.5f, (sb_lo[2] + sb_hi[2]) * 0.5f};
+        float radius = length(V3{c.x - sb_hi[0], c.y - sb_hi[1], c.z - sb_hi[2]});
+        const float PI_F = 3.14159265358979323846f;
+        for (DevLight& dl : lights) {
+            if (dl.kind == LK_DIRECTIONAL) dl.area_sum = dl.intensity * (PI_F * radius * radius);
         }
     }
     if (btris.empty()) { *err = "scene has no triangles"; return MI355PT_E_INVALID; }
@@ -263,6 +312,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     dev.n_lights = (uint32_t)lights.size(); dev.n_materials = (uint32_t)materials.size();
     dev.root = bvh.root;
     features = lights.size() == 1 ? 0u : FEAT_MLIGHT;
+    if (!delta_lights.empty()) features |= FEAT_DELTA;
     for (const HostInstance& inst : instances) {
         const DevMaterial& m = materials[inst.mat];
         if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | (m.roughness >= 1e-3f ? FEAT_ROUGH : 0u);

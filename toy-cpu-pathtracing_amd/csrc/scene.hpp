@@ -16,6 +16,7 @@ struct HostMesh {
     uint32_t n_vert = 0, n_tri = 0;
 };
 struct HostInstance { uint32_t geom, mat; float l2w[16]; };
+struct HostDeltaLight { mi355pt_light_desc d; uint32_t material; uint32_t after_instances; };   // hidden emissive material holds the spectrum
 
 struct BuildTri { float lo[3], hi[3], c[3]; };
 struct BvhOut {
@@ -42,6 +43,7 @@ struct SceneImpl {
     std::vector<mi355pt_material_desc> mat_descs;
     std::vector<DevMaterial> materials;
     std::vector<HostInstance> instances;
+    std::vector<HostDeltaLight> delta_lights;   // creation order; after_instances = instances.size() at creation (light_sampler.rs:163-180)
     // ---- lowered ----
     bool built = false;
     int device = -1;

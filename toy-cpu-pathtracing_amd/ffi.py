@@ -51,6 +51,14 @@ class MaterialDesc(C.Structure):
                 ("clearcoat_thickness", C.c_float), ("clearcoat_tint", Spectrum), ("k", Spectrum)]
 
 
+LIGHT_POINT, LIGHT_SPOT, LIGHT_DIRECTIONAL = 1, 2, 3
+
+
+class LightDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("intensity", C.c_float), ("angle_inner", C.c_float), ("angle_outer", C.c_float),
+                ("spectrum", Spectrum), ("local_to_world", C.c_float * 16)]
+
+
 class Camera(C.Structure):
     _fields_ = [("position", C.c_float * 3), ("direction", C.c_float * 3), ("up", C.c_float * 3),
                 ("fov_deg", C.c_float), ("width", C.c_uint32), ("height", C.c_uint32)]
@@ -91,7 +99,7 @@ def _ptr(a, ty):
 # every symbol include/mi355pt.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
-    "scene_add_material", "scene_add_instance", "scene_build", "render", "render_accum_device", "film_resolve_device",
+    "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_build", "render", "render_accum_device", "film_resolve_device",
     "quantize_u8", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "last_error", "version",
 ]
 
@@ -110,6 +118,7 @@ class Backend:
         f("scene_add_mesh").argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4 + [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         f("scene_add_material").argtypes = [C.c_void_p, C.POINTER(MaterialDesc), C.POINTER(C.c_uint32)]
         f("scene_add_instance").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        f("scene_add_delta_light").argtypes = [C.c_void_p, C.POINTER(LightDesc)]
         f("scene_build").argtypes = [C.c_void_p, C.POINTER(Camera)]
         f("probe_sobol").argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32)]
         f("probe_intersect").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float),
@@ -209,6 +218,13 @@ class SceneHandle:
         m = np.eye(4, dtype=np.float32) if local_to_world is None else np.asarray(local_to_world, dtype=np.float32)
         cols = np.ascontiguousarray(m.T.reshape(-1))   # column-major
         self.b.check(self.b.fn("scene_add_instance")(self.h, geom, mat, _ptr(cols, C.c_float)), "scene_add_instance")
+
+    def add_delta_light(self, kind, intensity, spectrum, local_to_world=None, angle_inner=0.0, angle_outer=0.0):
+        m = np.eye(4, dtype=np.float32) if local_to_world is None else np.asarray(local_to_world, dtype=np.float32)
+        d = LightDesc(); d.kind = kind; d.intensity = intensity; d.angle_inner = angle_inner; d.angle_outer = angle_outer
+        d.spectrum = spectrum
+        d.local_to_world = (C.c_float * 16)(*np.ascontiguousarray(m.T.reshape(-1)))   # column-major
+        self.b.check(self.b.fn("scene_add_delta_light")(self.h, C.byref(d)), "scene_add_delta_light")
 
     def build(self, cam):
         self.b.check(self.b.fn("scene_build")(self.h, C.byref(cam)), "scene_build")

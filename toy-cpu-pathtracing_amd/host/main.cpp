@@ -44,6 +44,8 @@ int main(int argc, char** argv) {
         Scene scene;
         switch (a.scene) {                                                              // main.rs:70-92
             case 0: load_scene_0(scene, camera); break;
+            case 1: load_scene_1(scene, camera); break;
+            case 2: load_scene_2(scene, camera); break;
             case 3: load_scene_3(scene, camera); break;
             case 6: load_scene_6(scene, camera); break;
             case 7: load_scene_7(scene, camera); break;
@@ -51,7 +53,7 @@ int main(int argc, char** argv) {
             case 8: load_scene_8(scene, camera); break;
             case 10: load_scene_10(scene, camera); break;
             case 17: load_scene_17(scene, camera); break;
-            default: std::fprintf(stderr, "scene %u is outside the MI355X hot-path scope (scenes 0, 3, 6, 7, 8, 10, 11, 17)\n", a.scene); return 2;
+            default: std::fprintf(stderr, "scene %u is outside the MI355X hot-path scope (scenes 0, 1, 2, 3, 6, 7, 8, 10, 11, 17)\n", a.scene); return 2;
         }
         std::puts("Start build scene.");                                                // main.rs:103-109
         auto t0 = std::chrono::steady_clock::now();

@@ -198,6 +198,8 @@ struct Transform {
     }
     static Transform from_scale(Vec3 v) { Transform s = identity(); s.m[0] = v.x; s.m[5] = v.y; s.m[10] = v.z; return s; }   // :119-122
     Transform scale(Vec3 v) const { Transform s = identity(); s.m[0] = v.x; s.m[5] = v.y; s.m[10] = v.z; return mul(s, *this); }
+    static Transform from_translate(Vec3 v) { return identity().translate(v); }                 // :94-97
+    static Transform from_rotate_y(float angle_rad) { return identity().rotate_y(angle_rad); }   // from_rotate(Quat::from_rotation_y(a)) :112-115
     Transform translate(Vec3 v) const { Transform t = identity(); t.m[12] = v.x; t.m[13] = v.y; t.m[14] = v.z; return mul(t, *this); }
 };
 
@@ -221,6 +223,34 @@ inline Vec3 v_cross(Vec3 a, Vec3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x -
 inline float v_dot(Vec3 a, Vec3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
 inline Vec3 v_norm(Vec3 a) { float r = 1.0f / std::sqrt(v_dot(a, a)); return {a.x * r, a.y * r, a.z * r}; }
 inline bool v_nan(Vec3 a) { return std::isnan(a.x) || std::isnan(a.y) || std::isnan(a.z); }
+
+// per-triangle tangents with the reference's fallback rules (geometry/impls/triangle_mesh.rs:181-226)
+inline void compute_tangents(TriangleMeshData& out) {
+    if (out.uv.empty()) return;
+    {
+        auto P = [&](uint32_t i) { return Vec3{out.pos[3 * i], out.pos[3 * i + 1], out.pos[3 * i + 2]}; };
+        auto fallback = [](Vec3 e1, Vec3 e2) {
+            Vec3 c = v_cross(e1, e2);
+            if (v_dot(c, c) < 1e-12f) return Vec3{1, 0, 0};
+            Vec3 n = v_norm(v_norm(c));
+            Vec3 cand = std::fabs(n.x) > 0.999f ? Vec3{0, 1, 0} : Vec3{1, 0, 0};
+            float pm = v_dot(n, cand);
+            return v_norm(Vec3{cand.x - n.x * pm, cand.y - n.y * pm, cand.z - n.z * pm});
+        };
+        for (size_t t = 0; t < out.idx.size() / 3; ++t) {
+            uint32_t i0 = out.idx[3 * t], i1 = out.idx[3 * t + 1], i2 = out.idx[3 * t + 2];
+            Vec3 e1 = v_sub(P(i1), P(i0)), e2 = v_sub(P(i2), P(i0));
+            float du1 = out.uv[2 * i1] - out.uv[2 * i0], dv1 = out.uv[2 * i1 + 1] - out.uv[2 * i0 + 1];
+            float du2 = out.uv[2 * i2] - out.uv[2 * i0], dv2 = out.uv[2 * i2 + 1] - out.uv[2 * i0 + 1];
+            float den = du1 * dv2 - dv1 * du2;
+            float r = 1.0f / den;
+            Vec3 tg{r * (e1.x * dv2 - e2.x * dv1), r * (e1.y * dv2 - e2.y * dv1), r * (e1.z * dv2 - e2.z * dv1)};
+            if (std::fabs(den) < 1e-6f) tg = fallback(e1, e2);
+            else { tg = v_norm(tg); if (v_nan(tg)) tg = fallback(e1, e2); }
+            out.tangent.insert(out.tangent.end(), {tg.x, tg.y, tg.z});
+        }
+    }
+}
 
 inline TriangleMeshData load_obj_file(const std::string& path) {
     std::ifstream f(path);
@@ -261,36 +291,18 @@ inline TriangleMeshData load_obj_file(const std::string& path) {
     }
     if (out.nrm.size() != out.pos.size()) throw std::runtime_error(path + ": every vertex needs a normal");
     if (!out.uv.empty() && out.uv.size() / 2 != out.pos.size() / 3) throw std::runtime_error(path + ": inconsistent texcoords");
-    // per-triangle tangents with the reference's fallback rules (:181-226)
-    if (!out.uv.empty()) {
-        auto P = [&](uint32_t i) { return Vec3{out.pos[3 * i], out.pos[3 * i + 1], out.pos[3 * i + 2]}; };
-        auto fallback = [](Vec3 e1, Vec3 e2) {
-            Vec3 c = v_cross(e1, e2);
-            if (v_dot(c, c) < 1e-12f) return Vec3{1, 0, 0};
-            Vec3 n = v_norm(v_norm(c));
-            Vec3 cand = std::fabs(n.x) > 0.999f ? Vec3{0, 1, 0} : Vec3{1, 0, 0};
-            float pm = v_dot(n, cand);
-            return v_norm(Vec3{cand.x - n.x * pm, cand.y - n.y * pm, cand.z - n.z * pm});
-        };
-        for (size_t t = 0; t < out.idx.size() / 3; ++t) {
-            uint32_t i0 = out.idx[3 * t], i1 = out.idx[3 * t + 1], i2 = out.idx[3 * t + 2];
-            Vec3 e1 = v_sub(P(i1), P(i0)), e2 = v_sub(P(i2), P(i0));
-            float du1 = out.uv[2 * i1] - out.uv[2 * i0], dv1 = out.uv[2 * i1 + 1] - out.uv[2 * i0 + 1];
-            float du2 = out.uv[2 * i2] - out.uv[2 * i0], dv2 = out.uv[2 * i2 + 1] - out.uv[2 * i0 + 1];
-            float den = du1 * dv2 - dv1 * du2;
-            float r = 1.0f / den;
-            Vec3 tg{r * (e1.x * dv2 - e2.x * dv1), r * (e1.y * dv2 - e2.y * dv1), r * (e1.z * dv2 - e2.z * dv1)};
-            if (std::fabs(den) < 1e-6f) tg = fallback(e1, e2);
-            else { tg = v_norm(tg); if (v_nan(tg)) tg = fallback(e1, e2); }
-            out.tangent.insert(out.tangent.end(), {tg.x, tg.y, tg.z});
-        }
-    }
+    compute_tangents(out);
     return out;
 }
 
 // ------------------------------------------------------------------ Scene
 struct GeometryIndex { uint32_t id; };
 struct GeometryPrimitive { GeometryIndex geometry_index; Material surface_material; Transform transform; };   // CreatePrimitiveDesc::GeometryPrimitive
+// CreatePrimitiveDesc::{SingleTriangle,PointLight,SpotLight,DirectionalLight}Primitive (primitive/create_desc.rs:17-66)
+struct SingleTrianglePrimitive { Vec3 positions[3]; Vec3 normals[3]; float uvs[3][2]; Material surface_material; Transform transform; };
+struct PointLightPrimitive { float intensity; Spectrum spectrum; Transform transform; };
+struct SpotLightPrimitive { float angle_inner, angle_outer, intensity; Spectrum spectrum; Transform transform; };
+struct DirectionalLightPrimitive { float intensity; Spectrum spectrum; Transform transform; };
 
 class Scene {
 public:
@@ -328,10 +340,31 @@ public:
         check(mi355pt_scene_add_material(s_, &md, &mat), "mi355pt_scene_add_material");
         check(mi355pt_scene_add_instance(s_, d.geometry_index.id, mat, d.transform.m), "mi355pt_scene_add_instance");
     }
+    void create_primitive(const SingleTrianglePrimitive& d) {      // lowered to a one-triangle mesh with load_obj's tangent rule
+        TriangleMeshData m;
+        for (int i = 0; i < 3; ++i) {
+            m.pos.insert(m.pos.end(), {d.positions[i].x, d.positions[i].y, d.positions[i].z});
+            m.nrm.insert(m.nrm.end(), {d.normals[i].x, d.normals[i].y, d.normals[i].z});
+            m.uv.insert(m.uv.end(), {d.uvs[i][0], d.uvs[i][1]});
+        }
+        m.idx = {0, 1, 2};
+        compute_tangents(m);
+        uint32_t id;
+        check(mi355pt_scene_add_mesh(s_, m.pos.data(), m.nrm.data(), m.uv.data(), m.tangent.data(), m.idx.data(), 3, 1, &id), "mi355pt_scene_add_mesh");
+        create_primitive(GeometryPrimitive{{id}, d.surface_material, d.transform});
+    }
+    void create_primitive(const PointLightPrimitive& d) { add_light(MI355PT_LIGHT_POINT, d.intensity, 0, 0, d.spectrum, d.transform); }
+    void create_primitive(const SpotLightPrimitive& d) { add_light(MI355PT_LIGHT_SPOT, d.intensity, d.angle_inner, d.angle_outer, d.spectrum, d.transform); }
+    void create_primitive(const DirectionalLightPrimitive& d) { add_light(MI355PT_LIGHT_DIRECTIONAL, d.intensity, 0, 0, d.spectrum, d.transform); }
     void build(const Camera& cam) { check(mi355pt_scene_build(s_, &cam.raw()), "mi355pt_scene_build"); }
     const mi355pt_scene* raw() const { return s_; }
 
 private:
+    void add_light(uint32_t kind, float intensity, float a_in, float a_out, const Spectrum& sp, const Transform& t) {
+        mi355pt_light_desc ld{}; ld.kind = kind; ld.intensity = intensity; ld.angle_inner = a_in; ld.angle_outer = a_out;
+        ld.spectrum = lower_spectrum(sp); std::memcpy(ld.local_to_world, t.m, sizeof(ld.local_to_world));
+        check(mi355pt_scene_add_delta_light(s_, &ld), "mi355pt_scene_add_delta_light");
+    }
     uint32_t add_tex(const ImageRgb8& im) { uint32_t id; check(mi355pt_scene_add_tex_rgb8(s_, im.rgb.data(), im.w, im.h, &id), "mi355pt_scene_add_tex_rgb8"); return id; }
     mi355pt_spectrum lower_spectrum(const Spectrum& sp) {
         mi355pt_spectrum s = sp.s;

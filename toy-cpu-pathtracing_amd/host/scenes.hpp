@@ -1,4 +1,4 @@
-// load_scene_N(&mut scene, &mut camera) of renderer/src/scene/scene_{0,3,6,7,8,10,11,17}.rs, call for call.
+// load_scene_N(&mut scene, &mut camera) of renderer/src/scene/scene_{0,1,2,3,6,7,8,10,11,17}.rs, call for call.
 // Asset paths keep the reference's names under $MI355PT_ASSETS (default ./assets); the files are the synthetic
 // stand-ins written by tools/export_assets.py (the reference's are git-LFS stubs), textures as binary PPM.
 #pragma once
@@ -12,7 +12,7 @@ inline std::string asset(const std::string& rel) {
 }
 
 // box / hidari / migi / yuka / oku / tenjou / light — identical in scenes 3, 8, 10, 17 (scene_3.rs:33-107)
-inline void load_room(Scene& scene) {
+inline void load_room(Scene& scene, bool with_light = true) {
     struct Wall { const char* obj; ColorSrgb c; };
     const Wall walls[] = {{"box.obj", {0.8f, 0.8f, 0.8f}}, {"hidari.obj", {0.9f, 0.0f, 0.0f}}, {"migi.obj", {0.0f, 0.9f, 0.0f}},
                           {"yuka.obj", {0.8f, 0.8f, 0.8f}}, {"oku.obj", {0.8f, 0.8f, 0.8f}}, {"tenjou.obj", {0.8f, 0.8f, 0.8f}}};
@@ -22,6 +22,7 @@ inline void load_room(Scene& scene) {
         scene.create_primitive(GeometryPrimitive{geom, LambertMaterial::create(SpectrumParameter::constant(spectrum), NormalParameter::none()),
                                                  Transform::identity()});
     }
+    if (!with_light) return;
     GeometryIndex geom = scene.load_obj(asset("light.obj"));
     scene.create_primitive(GeometryPrimitive{geom, EmissiveMaterial::create(SpectrumParameter::constant(presets::cie_illum_d6500()), FloatParameter::constant(10.0f)),
                                              Transform::identity()});
@@ -43,6 +44,33 @@ inline void load_scene_0(Scene& scene, Camera& camera) {            // scene_0.r
                                              Transform::identity()});
     load_room(scene);
     camera.set_look_to({0.0f, 3.15221f, 6.0f}, {0.0f, -0.9f, -3.2f}, {0.0f, 1.0f, 0.0f});
+}
+inline void load_scene_1(Scene& scene, Camera& camera) {            // scene_1.rs:12-87: point lights only
+    const float rad = 3.14159265358979323846f / 180.0f;
+    GeometryIndex geom = scene.load_obj(asset("bunny.obj"));
+    scene.create_primitive(GeometryPrimitive{geom, LambertMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.5f, 0.5f, 0.8f})), NormalParameter::none()),
+                                             Transform::identity()});
+    scene.create_primitive(GeometryPrimitive{geom, LambertMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.5f, 0.8f, 0.5f})), NormalParameter::none()),
+                                             Transform::from_rotate_y(30.0f * rad).translate({-1.0f, 1.0f, 3.0f})});
+    geom = scene.load_obj(asset("yuka.obj"));
+    scene.create_primitive(GeometryPrimitive{geom, LambertMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.8f, 0.8f, 0.8f})), NormalParameter::none()),
+                                             Transform::identity()});
+    scene.create_primitive(SingleTrianglePrimitive{{{-2.0f, 0.0f, 0.0f}, {2.0f, 0.0f, 0.0f}, {-2.0f, 4.0f, 0.0f}},
+                                                   {{0, 0, 1}, {0, 0, 1}, {0, 0, 1}},
+                                                   {{0.0f, 0.0f}, {1.0f, 0.0f}, {0.0f, 1.0f}},
+                                                   LambertMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.8f, 0.5f, 0.5f})), NormalParameter::none()),
+                                                   Transform::from_rotate_y(60.0f * rad)});
+    scene.create_primitive(PointLightPrimitive{10.0f, presets::cie_illum_d6500(), Transform::from_translate({0.0f, 3.0f, 0.0f})});
+    scene.create_primitive(PointLightPrimitive{10.0f, presets::cie_illum_d6500(), Transform::from_translate({3.0f, 5.0f, 0.0f})});
+    camera.set_look_to({0.0f, 3.5f, 7.0f}, {0.0f, -1.0f, -3.0f}, {0.0f, 1.0f, 0.0f});
+}
+inline void load_scene_2(Scene& scene, Camera& camera) {            // scene_2.rs:12-101: Cornell room lit by one point light
+    GeometryIndex geom = scene.load_obj(asset("bunny.obj"));
+    scene.create_primitive(GeometryPrimitive{geom, LambertMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.8f, 0.8f, 0.8f})), NormalParameter::none()),
+                                             Transform::identity()});
+    load_room(scene, false);
+    scene.create_primitive(PointLightPrimitive{10.0f, presets::cie_illum_d6500(), Transform::from_translate({0.0f, 3.0f, 0.0f})});
+    camera.set_look_to({0.0f, 3.5f, 6.0f}, {0.0f, -1.0f, -3.0f}, {0.0f, 1.0f, 0.0f});
 }
 inline void load_scene_6(Scene& scene, Camera& camera) {            // scene_6.rs:13-110: smooth gold hero
     GeometryIndex geom = scene.load_obj(asset("bunny.obj"));

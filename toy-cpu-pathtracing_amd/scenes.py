@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 from . import assets
-from .ffi import (HERE, MAT_CLEARCOAT, MAT_EMISSIVE, MAT_GLASS, MAT_LAMBERT, MAT_METAL, MAT_PLASTIC, MAT_SIMPLE_PBR, NONE, MaterialDesc,
+from .ffi import (HERE, LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_SPOT, MAT_CLEARCOAT, MAT_EMISSIVE, MAT_GLASS, MAT_LAMBERT, MAT_METAL, MAT_PLASTIC, MAT_SIMPLE_PBR, NONE, MaterialDesc,
                   Spectrum, make_camera)
 
 DATA = os.path.join(HERE, "data")
@@ -63,7 +63,21 @@ def lambert(color, normal_tex=NONE):
     return d
 
 
-def _room(scene, p, with_box=True):
+def _rot_y(deg):
+    """Mat4::from_quat(Quat::from_rotation_y(deg.to_radians())) in f32, glam's formula (1 - y*(y+y), w*(y+y))."""
+    a = np.float32(np.float32(deg) * np.float32(np.pi / 180.0))
+    y, w = np.float32(np.sin(a * np.float32(0.5))), np.float32(np.cos(a * np.float32(0.5)))
+    y2 = np.float32(y + y); yy = np.float32(y * y2); wy = np.float32(w * y2)
+    c, s = np.float32(np.float32(1.0) - yy), wy
+    return np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], dtype=np.float32)
+
+
+def _translate(x, y, z):
+    m = np.eye(4, dtype=np.float32); m[:3, 3] = np.array([x, y, z], dtype=np.float32)
+    return m
+
+
+def _room(scene, p, with_box=True, with_light=True):
     """box/hidari/migi/yuka/oku/tenjou/light — scene_3.rs:33-107 (identical in scenes 8, 10, 17)."""
     room = _asset("room")
     grey = Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8)
@@ -74,6 +88,8 @@ def _room(scene, p, with_box=True):
             continue
         g = scene.add_mesh(room[name])
         scene.add_instance(g, scene.add_material(lambert(col)))
+    if not with_light:
+        return
     d65 = scene.add_lut470(p["cie_illum_d6500"])
     em = MaterialDesc(); em.type = MAT_EMISSIVE; em.color = Spectrum.lut(d65); em.intensity = 10.0; em.normal_tex = NONE
     g = scene.add_mesh(room["light"])
@@ -124,6 +140,35 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         d.normal_tex = NONE; d.thin = 1; d.roughness = 0.0
         scene.add_instance(g, scene.add_material(d))
         _room(scene, p)
+        cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 1:    # scene_1.rs:12-87: two Lambert heroes, floor, one triangle, two D65 point lights (no area light)
+        g = scene.add_mesh(_asset("bunny"))
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.5, 0.5, 0.8))))
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.5, 0.8, 0.5))),
+                           (_translate(-1.0, 1.0, 3.0) @ _rot_y(30.0)).astype(np.float32))      # from_rotate(..).translate(..) = T * R
+        room = _asset("room")
+        scene.add_instance(scene.add_mesh(room["yuka"]), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        tri = assets.load_obj_semantics(assets.single_triangle())                                # SingleTrianglePrimitive :46-67
+        scene.add_instance(scene.add_mesh(tri), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.5, 0.5))), _rot_y(60.0))
+        d65 = Spectrum.lut(scene.add_lut470(p["cie_illum_d6500"]))
+        scene.add_delta_light(LIGHT_POINT, 10.0, d65, _translate(0.0, 3.0, 0.0))
+        scene.add_delta_light(LIGHT_POINT, 10.0, d65, _translate(3.0, 5.0, 0.0))
+        cam = make_camera((0.0, 3.5, 7.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 2:    # scene_2.rs:12-101: Lambert hero in the Cornell room lit by one D65 point light
+        g = scene.add_mesh(_asset("bunny"))
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        _room(scene, p, with_light=False)
+        scene.add_delta_light(LIGHT_POINT, 10.0, Spectrum.lut(scene.add_lut470(p["cie_illum_d6500"])), _translate(0.0, 3.0, 0.0))
+        cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 21:   # not a reference scene: scene 2's room lit by a spot light, a directional light AND the area light
+        g = scene.add_mesh(_asset("bunny"))
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        d65 = Spectrum.lut(scene.add_lut470(p["cie_illum_d6500"]))
+        # spot light above the hero looking down (-y): local +z -> world -y is a rotation about x by +90 deg
+        rx = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=np.float32)
+        scene.add_delta_light(LIGHT_SPOT, 30.0, d65, (_translate(0.5, 3.5, -0.5) @ rx).astype(np.float32), angle_inner=0.9, angle_outer=0.6)
+        _room(scene, p)
+        scene.add_delta_light(LIGHT_DIRECTIONAL, 0.5, d65, (_rot_y(200.0) @ rx).astype(np.float32))
         cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
     elif scene_id in (6, 7):     # scene_6.rs:16-26: smooth gold hero; scene_7.rs:16-39: four gold heroes, roughness 0.05..0.75
         g = scene.add_mesh(_asset("bunny"))
