@@ -16,12 +16,15 @@
 //
 // Error behaviour: the reference panics; this layer throws std::runtime_error carrying mi355pt_last_error().
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -110,8 +113,171 @@ inline ImageRgb8 load_ppm(const std::string& path) {
     if (!f) throw std::runtime_error(path + ": truncated");
     return im;
 }
-struct RgbTexture { std::shared_ptr<ImageRgb8> img; static RgbTexture load_srgb(const std::string& p) { return {std::make_shared<ImageRgb8>(load_ppm(p))}; } };
-struct NormalTexture { std::shared_ptr<ImageRgb8> img; bool flip_y; static NormalTexture load(const std::string& p, bool flip_y) { return {std::make_shared<ImageRgb8>(load_ppm(p)), flip_y}; } };
+// ---- PNG decoding (the reference's texture/loader.rs:44-64 goes through image::open(..).to_rgb8()): 8- and 16-bit,
+// grey / grey+alpha / RGB / RGBA / palette, non-interlaced, own inflate (RFC 1950/1951) so the host mirror needs no libpng/zlib.
+namespace png_detail {
+struct BitReader {
+    const uint8_t* p; size_t n, pos = 0; uint32_t bitbuf = 0; int bitcnt = 0;
+    uint32_t bits(int c) {
+        while (bitcnt < c) { if (pos >= n) throw std::runtime_error("png: truncated deflate stream"); bitbuf |= (uint32_t)p[pos++] << bitcnt; bitcnt += 8; }
+        uint32_t v = c ? (bitbuf & ((1u << c) - 1u)) : 0u; bitbuf >>= c; bitcnt -= c; return v;
+    }
+    void align() { bitbuf = 0; bitcnt = 0; }
+};
+struct Huffman {
+    uint16_t count[16] = {0}; std::vector<uint16_t> symbol;
+    void build(const uint8_t* len, int n) {
+        symbol.assign(n, 0);
+        for (int i = 0; i < 16; ++i) count[i] = 0;
+        for (int i = 0; i < n; ++i) count[len[i]]++;
+        count[0] = 0;
+        uint16_t offs[16]; offs[1] = 0;
+        for (int i = 1; i < 15; ++i) offs[i + 1] = offs[i] + count[i];
+        for (int i = 0; i < n; ++i) if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+    }
+    int decode(BitReader& br) const {
+        int code = 0, first = 0, index = 0;
+        for (int l = 1; l <= 15; ++l) {
+            code |= (int)br.bits(1);
+            int c = count[l];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        throw std::runtime_error("png: bad Huffman code");
+    }
+};
+inline std::vector<uint8_t> inflate(const uint8_t* data, size_t n) {
+    if (n < 6) throw std::runtime_error("png: zlib stream too short");
+    BitReader br{data + 2, n - 2};   // skip CMF/FLG
+    std::vector<uint8_t> out;
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (bool last = false; !last;) {
+        last = br.bits(1) != 0;
+        uint32_t type = br.bits(2);
+        if (type == 0) {
+            br.align();
+            if (br.pos + 4 > br.n) throw std::runtime_error("png: truncated stored block");
+            uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8); br.pos += 4;
+            if (br.pos + len > br.n) throw std::runtime_error("png: truncated stored block");
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len); br.pos += len;
+            continue;
+        }
+        if (type == 3) throw std::runtime_error("png: bad deflate block type");
+        Huffman lit, dist;
+        if (type == 1) {
+            uint8_t l[320]; int i = 0;
+            for (; i < 144; ++i) l[i] = 8;
+            for (; i < 256; ++i) l[i] = 9;
+            for (; i < 280; ++i) l[i] = 7;
+            for (; i < 288; ++i) l[i] = 8;
+            lit.build(l, 288);
+            for (i = 0; i < 30; ++i) l[i] = 5;
+            dist.build(l, 30);
+        } else {
+            int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t l[320] = {0};
+            for (int i = 0; i < ncode; ++i) l[order[i]] = (uint8_t)br.bits(3);
+            Huffman cl; cl.build(l, 19);
+            uint8_t lens[320] = {0};
+            for (int i = 0; i < nlen + ndist;) {
+                int sym = cl.decode(br);
+                if (sym < 16) lens[i++] = (uint8_t)sym;
+                else {
+                    int rep; uint8_t v = 0;
+                    if (sym == 16) { if (i == 0) throw std::runtime_error("png: bad code lengths"); v = lens[i - 1]; rep = 3 + (int)br.bits(2); }
+                    else if (sym == 17) rep = 3 + (int)br.bits(3);
+                    else rep = 11 + (int)br.bits(7);
+                    if (i + rep > nlen + ndist) throw std::runtime_error("png: bad code lengths");
+                    while (rep--) lens[i++] = v;
+                }
+            }
+            lit.build(lens, nlen); dist.build(lens + nlen, ndist);
+        }
+        for (;;) {
+            int sym = lit.decode(br);
+            if (sym < 256) out.push_back((uint8_t)sym);
+            else if (sym == 256) break;
+            else {
+                sym -= 257;
+                if (sym >= 29) throw std::runtime_error("png: bad length symbol");
+                uint32_t len = lbase[sym] + br.bits(lext[sym]);
+                int ds = dist.decode(br);
+                if (ds >= 30) throw std::runtime_error("png: bad distance symbol");
+                uint32_t d = dbase[ds] + br.bits(dext[ds]);
+                if (d > out.size()) throw std::runtime_error("png: distance too far back");
+                size_t from = out.size() - d;
+                for (uint32_t k = 0; k < len; ++k) out.push_back(out[from + k]);
+            }
+        }
+    }
+    return out;
+}
+}  // namespace png_detail
+inline ImageRgb8 load_png(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open texture " + path);
+    std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (d.size() < 8 || std::memcmp(d.data(), sig, 8) != 0) throw std::runtime_error(path + ": not a PNG (a git-LFS pointer stub?)");
+    auto be32 = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
+    uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    for (size_t o = 8; o + 12 <= d.size();) {
+        uint32_t len = be32(o); std::string type((const char*)&d[o + 4], 4);
+        if (o + 12 + len > d.size()) throw std::runtime_error(path + ": truncated chunk");
+        const uint8_t* body = &d[o + 8];
+        if (type == "IHDR") { w = be32(o + 8); h = be32(o + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        else if (type == "PLTE") plte.assign(body, body + len);
+        else if (type == "IDAT") idat.insert(idat.end(), body, body + len);
+        else if (type == "IEND") break;
+        o += 12 + len;
+    }
+    if (!w || !h || interlace) throw std::runtime_error(path + ": unsupported PNG (interlaced or empty)");
+    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch || !(depth == 8 || depth == 16 || (ctype == 3 && depth <= 8) || (ctype == 0 && depth <= 8))) throw std::runtime_error(path + ": unsupported PNG colour type");
+    std::vector<uint8_t> raw = png_detail::inflate(idat.data(), idat.size());
+    size_t bpp = std::max<size_t>(1, (size_t)ch * depth / 8), stride = ((size_t)w * ch * depth + 7) / 8;
+    if (raw.size() < (stride + 1) * h) throw std::runtime_error(path + ": image data too short");
+    std::vector<uint8_t> cur(stride), prev(stride, 0);
+    ImageRgb8 im; im.w = w; im.h = h; im.rgb.resize((size_t)w * h * 3);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* line = &raw[(stride + 1) * y];
+        int ft = line[0];
+        for (size_t i = 0; i < stride; ++i) {
+            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = line[1 + i];
+            int v;
+            switch (ft) {
+                case 0: v = x; break; case 1: v = x + a; break; case 2: v = x + b; break; case 3: v = x + ((a + b) >> 1); break;
+                case 4: { int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c); v = x + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)); break; }
+                default: throw std::runtime_error(path + ": bad PNG filter");
+            }
+            cur[i] = (uint8_t)v;
+        }
+        for (uint32_t x = 0; x < w; ++x) {
+            uint8_t* o = &im.rgb[((size_t)y * w + x) * 3];
+            auto sample = [&](int k) -> uint8_t {           // k-th channel of pixel x as 8 bits (16-bit: high byte, like image's to_rgb8 up to rounding)
+                if (depth == 16) return cur[((size_t)x * ch + k) * 2];
+                if (depth == 8) return cur[(size_t)x * ch + k];
+                size_t bit = (size_t)x * depth; int v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                return ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+            };
+            if (ctype == 3) { size_t i = sample(0); if (3 * i + 2 >= plte.size()) throw std::runtime_error(path + ": palette index out of range"); o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2]; }
+            else if (ch <= 2) { o[0] = o[1] = o[2] = sample(0); }
+            else { o[0] = sample(0); o[1] = sample(1); o[2] = sample(2); }
+        }
+        std::swap(cur, prev);
+    }
+    return im;
+}
+inline ImageRgb8 load_image(const std::string& path) {      // by extension: .png like the reference's assets, .ppm for the synthetic stand-ins
+    return path.size() >= 4 && path.compare(path.size() - 4, 4, ".png") == 0 ? load_png(path) : load_ppm(path);
+}
+struct RgbTexture { std::shared_ptr<ImageRgb8> img; static RgbTexture load_srgb(const std::string& p) { return {std::make_shared<ImageRgb8>(load_image(p))}; } };
+struct NormalTexture { std::shared_ptr<ImageRgb8> img; bool flip_y; static NormalTexture load(const std::string& p, bool flip_y) { return {std::make_shared<ImageRgb8>(load_image(p)), flip_y}; } };
 enum class SpectrumType { Albedo };
 
 // ------------------------------------------------------------------ parameters (scene/src/material/parameter.rs)
