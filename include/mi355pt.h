@@ -150,6 +150,12 @@ int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, co
 /* Scene::create_primitive(CreatePrimitiveDesc::{Point,Spot,Directional}LightPrimitive{..})  scene.rs:57-61.  Lights and
  * emissive instances enter the light sampler in creation order (light_sampler.rs:163-180). */
 int mi355pt_scene_add_delta_light(mi355pt_scene* s, const mi355pt_light_desc* desc);
+/* CreatePrimitiveDesc::EnvironmentLightPrimitive{intensity, texture, transform} (create_desc.rs:67-76;
+ * primitive/impls/environment_light.rs): lat-long float RGB map (row 0 = +y pole, the reference reads an EXR through
+ * image::open(..).to_rgb32f()), importance-sampled by luminance * sin(theta).  `illuminant_lut` is the LUT470 id of
+ * presets::cie_illum_d6500() (rgb_illuminant_spectrum.rs:28).  Only the rotation of the transform matters. */
+int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const float* rgb, uint32_t width, uint32_t height,
+                                        const float local_to_world[16], uint32_t illuminant_lut);
 /* Scene::build(&camera): world->render translation, BVH build, light list; uploads to the current HIP device.
  * scene.rs:64-76 */
 int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam);

@@ -162,6 +162,30 @@ struct PathTracer {
         *contrib = f * rad.radiance * g / (rad.pdf * light_prob);
     }
 
+    // Scene::evaluate_infinite_light_radiance (scene.rs:208-224)
+    SS infinite_radiance(V3 dir, const Wavelengths& wl) const {
+        SS total = SS::zero();
+        for (const EnvLight& e : scene.env_lights) total = total + e.direction_radiance(scene.table, dir, wl);
+        return total;
+    }
+    // evaluate_infinite_light{,_with_mis} (common.rs:174-241) after EnvironmentLight::sample_infinite_light (:317-340)
+    void eval_env_light(const EnvLight& e, V2 luv, const SurfaceInteraction& sp, const Material& mat, const Wavelengths& wl, V3 wo_render,
+                        const M4& r2t, float light_prob, bool mis, SS* contrib, float* weight, Counters* c, uint64_t mc_key) const {
+        V3 wi_r; float pdf_dir;
+        e.sample(luv.x, luv.y, &wi_r, &pdf_dir);
+        SS radiance = e.direction_radiance(scene.table, wi_r, wl);
+        *contrib = SS::zero(); *weight = 1.0f;
+        Ray shadow = move_forward(Ray{sp.position, wi_r}, SHADOW_EPS);
+        if (scene.intersect_p(shadow, std::numeric_limits<float>::max(), c)) return;
+        MaterialEval me{scene, c};
+        me.mc_key = mc_key;
+        ShadingPoint spt{transform_normal(r2t, sp.normal), sp.uv};
+        V3 wo = transform_vector3(r2t, wo_render), wi = transform_vector3(r2t, wi_r);
+        SS f = me.evaluate(mat, wl, wo, wi, spt);
+        if (mis) *weight = balance_heuristic(pdf_dir, me.pdf(mat, wl, wo, wi, spt));
+        *contrib = f * radiance / (pdf_dir * light_prob);
+    }
+
     // evaluate_delta_point_light / evaluate_delta_directional_light (common.rs:23-79) for PointLight, SpotLight
     // (PrimitiveDeltaPointLight, {point,spot}_light.rs) and DirectionalLight (directional_light.rs:95-107); MIS weight 1.
     SS eval_delta_light(const DeltaLight& d, const SurfaceInteraction& sp, const Material& mat, const Wavelengths& wl, V3 wo_render,
@@ -211,7 +235,10 @@ struct PathTracer {
         Intersection hit;
         if (c) c->samples++;
         auto finish = [&]() { if (c) c->sampler_draws += smp.draws; *wl_out = wl; return L; };
-        if (!scene.intersect(ray, std::numeric_limits<float>::max(), &hit, c)) return finish();   // no infinite lights in scope
+        if (!scene.intersect(ray, std::numeric_limits<float>::max(), &hit, c)) {                  // base_renderer.rs:180-187
+            L = L + T * infinite_radiance(ray.d, wl);
+            return finish();
+        }
         SS le;
         if (emissive_radiance(hit.interaction, wl, c, &le)) L = L + T * le;
         MaterialEval me{scene, c};
@@ -234,7 +261,12 @@ struct PathTracer {
                 if (ls.sample_light(ul, &lprim, &lprob)) {
                     float s = smp.get_1d();
                     V2 luv = smp.get_2d();
-                    if (lprim < 0) {                                                        // Scene::calculate_light (scene.rs:114-139)
+                    if (Scene::is_env(lprim)) {
+                        SS contrib; float w;
+                        eval_env_light(scene.env_lights[Scene::ENV_BASE - lprim], luv, hit.interaction, mat, wl, hit.wo, r2t, lprob,
+                                       prm.strategy == STRAT_MIS, &contrib, &w, c, me.mc_key);
+                        L = L + (T * contrib) * w;
+                    } else if (lprim < 0) {                                                 // Scene::calculate_light (scene.rs:114-139)
                         SS contrib = eval_delta_light(scene.delta_lights[-1 - lprim], hit.interaction, mat, wl, hit.wo, r2t, lprob, c, me.mc_key);
                         L = L + (T * contrib) * 1.0f;
                     } else {
@@ -254,7 +286,23 @@ struct PathTracer {
             V3 origin = hit.interaction.position + sign * n * RAY_EPS;
             Ray next = move_forward(Ray{origin, wi_render}, RAY_EPS);
             Intersection nh;
-            if (!scene.intersect(next, std::numeric_limits<float>::max(), &nh, c)) break;
+            if (!scene.intersect(next, std::numeric_limits<float>::max(), &nh, c)) {
+                // calculate_bsdf_infinite_light_contribution: PT adds f*Le/pdf (pt_renderer.rs:50-82), NEE nothing
+                // (nee_renderer.rs:139-153), MIS weights it with the summed infinite-light pdf (mis_renderer.rs:183-230)
+                if (!scene.env_lights.empty() && prm.strategy != STRAT_NEE) {
+                    SS radiance = infinite_radiance(next.d, wl);
+                    if (prm.strategy == STRAT_PT) L = L + T * ms.f * radiance / ms.pdf;
+                    else {
+                        LightSampler ls(scene, wl);
+                        float light_pdf = 0.0f;
+                        for (size_t k = 0; k < scene.env_lights.size(); ++k)
+                            light_pdf += ls.probability_infinite(Scene::ENV_BASE - (int)k) * scene.env_lights[k].direction_pdf(next.d);
+                        float w = balance_heuristic(ms.pdf, light_pdf);
+                        L = L + T * ms.f * radiance * tf * w;
+                    }
+                }
+                break;
+            }
             SS next_emissive = SS::zero();
             SS nle;
             if (emissive_radiance(nh.interaction, wl, c, &nle)) next_emissive = ms.f * nle * tf;

@@ -119,6 +119,110 @@ struct DeltaLight {
     uint32_t seq = 0;             // creation order among all primitives (light_list order, light_sampler.rs:163-180)
 };
 
+// EnvironmentLight (primitive/impls/environment_light.rs): lat-long float RGB texture, luminance * sin(theta) 2-D CDF
+struct EnvLight {
+    float intensity = 1.0f;
+    uint32_t w = 0, h = 0;
+    std::vector<float> rgb;                         // h * w * 3, row 0 = theta 0 (+y)
+    std::vector<float> marginal, conditional;       // h, h * w
+    float total_weight = 0.0f;
+    Spectrum integrated;                            // RgbIlluminantSpectrum of the mean colour (:44-61)
+    const float* illuminant = nullptr;              // presets::cie_illum_d6500()
+    M4 local_to_world = M4::identity(), local_to_render = M4::identity();
+    uint32_t seq = 0;
+
+    static Spectrum rgb_illuminant(const Rgb2SpecTable& table, const float rgb[3], const float* illum) {   // rgb_illuminant_spectrum.rs:26-41
+        Spectrum s; s.kind = SPEC_RGB_ILLUMINANT; s.lut = illum;
+        float mx = std::fmax(rgb[0], std::fmax(rgb[1], rgb[2]));
+        s.scale = 2.0f * mx;
+        if (s.scale == 0.0f) { s.kind = SPEC_CONSTANT; s.c[0] = 0.0f; return s; }   // black texel: 0 instead of the reference's 0/0
+        float scaled[3] = {rgb[0] / s.scale, rgb[1] / s.scale, rgb[2] / s.scale};
+        table.get_srgb_encoded(scaled, s.c);
+        return s;
+    }
+    void build(const Rgb2SpecTable& table) {                                                      // :28-75,153-199
+        float tot[3] = {0, 0, 0};
+        for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) for (int c = 0; c < 3; ++c) tot[c] += rgb[((size_t)y * w + x) * 3 + c];
+        float n = (float)(w * h);
+        for (int c = 0; c < 3; ++c) tot[c] /= n;
+        integrated = rgb_illuminant(table, tot, illuminant);
+        std::vector<float> row_w(h, 0.0f);
+        conditional.assign((size_t)w * h, 0.0f); marginal.assign(h, 0.0f);
+        for (uint32_t y = 0; y < h; ++y) {
+            float row_sum = 0.0f;
+            for (uint32_t x = 0; x < w; ++x) {
+                float v = ((float)y + 0.5f) / (float)h;
+                float theta = v * PI_F;
+                const float* p = &rgb[((size_t)y * w + x) * 3];
+                float lum = 0.299f * p[0] + 0.587f * p[1] + 0.114f * p[2];
+                float wgt = lum * std::fmax(std::sin(theta), 1e-8f);
+                row_sum += wgt;
+                conditional[(size_t)y * w + x] = row_sum;
+            }
+            row_w[y] = row_sum;
+            if (row_sum > 0.0f) for (uint32_t x = 0; x < w; ++x) conditional[(size_t)y * w + x] /= row_sum;
+        }
+        total_weight = 0.0f;
+        for (float r : row_w) total_weight += r;
+        float cum = 0.0f;
+        for (uint32_t y = 0; y < h; ++y) { cum += row_w[y]; marginal[y] = total_weight > 0.0f ? cum / total_weight : (float)(y + 1) / (float)h; }
+    }
+    static uint32_t sample_cdf(const float* cdf, uint32_t n, float u) {          // binary_search_by: insertion point, clamped (:201-206)
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (cdf[mid] < u) lo = mid + 1; else hi = mid; }
+        return std::min(lo, n - 1);
+    }
+    static void dir_to_spherical(V3 d, float* theta, float* phi) {               // :96-103
+        *theta = std::fmin(std::fmax(std::acos(d.y), 0.0f), PI_F);
+        float p = std::atan2(d.z, d.x);
+        if (p < 0.0f) p += 2.0f * PI_F;
+        *phi = p;
+    }
+    void texel(uint32_t x, uint32_t y, float out[3]) const { const float* p = &rgb[((size_t)y * w + x) * 3]; out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; }
+    void sample_texture(float u, float v, float out[3]) const {                   // :113-151
+        u = std::fmin(std::fmax(u, 0.0f), 1.0f); v = std::fmin(std::fmax(v, 0.0f), 1.0f);
+        float x = u * (float)(w - 1), y = v * (float)(h - 1);
+        uint32_t x0 = (uint32_t)std::floor(x), y0 = (uint32_t)std::floor(y);
+        uint32_t x1 = std::min(x0 + 1, w - 1), y1 = std::min(y0 + 1, h - 1);
+        float fx = x - (float)x0, fy = y - (float)y0;
+        float p00[3], p01[3], p10[3], p11[3];
+        texel(x0, y0, p00); texel(x1, y0, p01); texel(x0, y1, p10); texel(x1, y1, p11);
+        for (int c = 0; c < 3; ++c) {
+            float p0 = p00[c] * (1.0f - fx) + p01[c] * fx, p1 = p10[c] * (1.0f - fx) + p11[c] * fx;
+            out[c] = p0 * (1.0f - fy) + p1 * fy;
+        }
+    }
+    float direction_pdf(V3 dir_render) const {                                   // :212-238
+        if (total_weight <= 0.0f) return 0.0f;
+        V3 dl = transform_vector3(inverse(local_to_render), dir_render);
+        float theta, phi; dir_to_spherical(dl, &theta, &phi);
+        float u = phi / (2.0f * PI_F), v = theta / PI_F;
+        uint32_t x = std::min((uint32_t)std::floor(u * (float)w), w - 1), y = std::min((uint32_t)std::floor(v * (float)h), h - 1);
+        float p[3]; texel(x, y, p);
+        float lum = 0.299f * p[0] + 0.587f * p[1] + 0.114f * p[2];
+        float st = std::fmax(std::sin(theta), 1e-8f);
+        float pdf_tex = (lum * st) / total_weight;
+        float jac = (float)w * (float)h / (2.0f * PI_F * PI_F * st);
+        return pdf_tex * jac;
+    }
+    SS direction_radiance(const Rgb2SpecTable& table, V3 dir_render, const Wavelengths& wl) const {   // :292-305
+        V3 dl = transform_vector3(inverse(local_to_render), dir_render);
+        float theta, phi; dir_to_spherical(dl, &theta, &phi);
+        float rgbv[3];
+        sample_texture(phi / (2.0f * PI_F), theta / PI_F, rgbv);
+        return rgb_illuminant(table, rgbv, illuminant).sample(wl) * intensity;
+    }
+    void sample(float ux, float uy, V3* wi, float* pdf_dir) const {              // :317-340
+        uint32_t y = sample_cdf(marginal.data(), h, ux);
+        uint32_t x = sample_cdf(&conditional[(size_t)y * w], w, uy);
+        float u = ((float)x + 0.5f) / (float)w, v = ((float)y + 0.5f) / (float)h;
+        float theta = v * PI_F, phi = u * 2.0f * PI_F;
+        V3 wl{std::sin(theta) * std::cos(phi), std::cos(theta), std::sin(theta) * std::sin(phi)};
+        *wi = transform_vector3(local_to_render, wl);
+        *pdf_dir = direction_pdf(*wi);
+    }
+};
+
 struct Counters {
     TraversalCounters closest_tlas, closest_blas, any_tlas, any_blas;
     uint64_t closest_rays = 0, shadow_rays = 0, closest_hits = 0, bounces = 0, samples = 0, sampler_draws = 0;
@@ -140,6 +244,7 @@ struct Scene {
     std::vector<Material> materials;
     std::vector<Primitive> primitives;
     std::vector<DeltaLight> delta_lights;
+    std::vector<EnvLight> env_lights;             // light_list entries <= ENV_BASE - k
     uint32_t next_seq = 0;
     std::vector<int> light_list;                  // LightSamplerFactory::light_list: >= 0 primitive index, < 0 delta light -1-k
     Bvh tlas;
@@ -192,6 +297,12 @@ struct Scene {
             d.local_to_render = world_to_render * d.local_to_world;
             d.area = PI_F * radius * radius;
             order.push_back({d.seq, -1 - (int)k});
+        }
+        for (size_t k = 0; k < env_lights.size(); ++k) {
+            EnvLight& e = env_lights[k];
+            e.local_to_render = world_to_render * e.local_to_world;
+            e.build(table);
+            order.push_back({e.seq, ENV_BASE - (int)k});
         }
         std::sort(order.begin(), order.end());
         for (auto& o : order) light_list.push_back(o.second);
@@ -254,7 +365,10 @@ struct Scene {
 
     // ---- lights ----
     // EmissiveMaterial::average_intensity * area_sum (emissive_material.rs:63-79, emissive_triangle_mesh.rs:166-173)
+    static constexpr int ENV_BASE = -1000000;       // light_list entry of environment light k is ENV_BASE - k
+    static bool is_env(int entry) { return entry <= ENV_BASE; }
     SS light_phi(int prim, const Wavelengths& w) const {
+        if (is_env(prim)) { const EnvLight& e = env_lights[ENV_BASE - prim]; return e.intensity * e.integrated.sample(w); }   // :287-290
         if (prim < 0) {
             const DeltaLight& d = delta_lights[-1 - prim];
             SS s = d.spectrum.sample(w);
@@ -293,6 +407,15 @@ struct LightSampler {
         size_t l = table.size() - 1;
         *prim = scene->light_list[l]; *prob = weights[l] / weight_sum;
         return true;
+    }
+    // probability_infinite_light (light_sampler.rs:115-153): weight / sum of the INFINITE lights' weights
+    float probability_infinite(int entry) const {
+        if (table.empty() || weight_sum == 0.0f) return 0.0f;
+        float inf_sum = 0.0f;
+        for (size_t i = 0; i < scene->light_list.size(); ++i) if (Scene::is_env(scene->light_list[i])) inf_sum += weights[i];
+        if (inf_sum == 0.0f) return 0.0f;
+        for (size_t i = 0; i < scene->light_list.size(); ++i) if (scene->light_list[i] == entry) return weights[i] / inf_sum;
+        return 0.0f;
     }
     float probability(int prim) const {
         if (table.empty() || weight_sum == 0.0f) return 0.0f;

@@ -166,15 +166,22 @@ static inline float sigmoid_poly_value(const float c[3], float lambda) {   // :1
 }
 
 // -------- Spectrum (dyn SpectrumTrait) --------
-enum SpectrumKind : uint32_t { SPEC_CONSTANT = 0, SPEC_SIGMOID = 1, SPEC_LUT470 = 2 };
+enum SpectrumKind : uint32_t { SPEC_CONSTANT = 0, SPEC_SIGMOID = 1, SPEC_LUT470 = 2, SPEC_RGB_ILLUMINANT = 3 };
 struct Spectrum {
     uint32_t kind = SPEC_CONSTANT;
     float c[3] = {0, 0, 0};              // constant value in c[0], or sigmoid coefficients
-    const float* lut = nullptr;          // 470 entries
+    const float* lut = nullptr;          // 470 entries (SPEC_RGB_ILLUMINANT: the illuminant, presets::cie_illum_d6500())
+    float scale = 1.0f;                  // SPEC_RGB_ILLUMINANT: 2 * max(rgb)
+    static float lut_value(const float* lut, float lambda) {
+        if (!(lambda >= LAMBDA_MIN && lambda <= LAMBDA_MAX)) return 0.0f;
+        int idx = (int)std::floor(lambda - LAMBDA_MIN);
+        return idx < NLUT ? lut[idx] : 0.0f;
+    }
     float value(float lambda) const {
         switch (kind) {
             case SPEC_CONSTANT: return c[0];                                    // constant_spectrum.rs:17-19
             case SPEC_SIGMOID: return sigmoid_poly_value(c, lambda);
+            case SPEC_RGB_ILLUMINANT: return scale * sigmoid_poly_value(c, lambda) * lut_value(lut, lambda);   // rgb_illuminant_spectrum.rs:44-46
             default: {                                                          // densely_sampled_spectrum.rs:57-67
                 if (!(lambda >= LAMBDA_MIN && lambda <= LAMBDA_MAX)) return 0.0f;
                 int idx = (int)std::floor(lambda - LAMBDA_MIN);

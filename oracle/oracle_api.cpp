@@ -127,6 +127,16 @@ int ptoracle_scene_add_delta_light(ptoracle_scene* s, const mi355pt_light_desc* 
     s->scene.delta_lights.push_back(l);
     return 0;
 }
+int ptoracle_scene_add_environment_light(ptoracle_scene* s, float intensity, const float* rgb, uint32_t w, uint32_t h, const float* l2w,
+                                         uint32_t illuminant_lut) {
+    if (!rgb || w == 0 || h == 0 || illuminant_lut >= s->scene.luts.size()) return -1;
+    EnvLight e; e.intensity = intensity; e.w = w; e.h = h; e.rgb.assign(rgb, rgb + (size_t)w * h * 3);
+    e.illuminant = s->scene.luts[illuminant_lut].data();
+    e.local_to_world = M4::from_cols16(l2w);
+    e.seq = s->scene.next_seq++;
+    s->scene.env_lights.push_back(std::move(e));
+    return 0;
+}
 int ptoracle_scene_build(ptoracle_scene* s, const mi355pt_camera* cam) {
     if (s->scene.primitives.empty()) return -1;
     s->scene.build(V3{cam->position[0], cam->position[1], cam->position[2]});

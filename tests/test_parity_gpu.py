@@ -154,13 +154,13 @@ def test_gpu_pt_nee_mis_consistency_metal(product, pkg):
 
 @pytest.mark.parametrize("scene_id,strategy", [(8, "mis"), (10, "mis"), (0, "nee"), (17, "nee"), (17, "mis"), (11, "mis"), (11, "nee"),
                                                (6, "mis"), (7, "mis"), (7, "nee"), (20, "mis"), (20, "pt"),
-                                               (1, "nee"), (2, "mis"), (21, "mis"), (21, "nee")])
+                                               (1, "nee"), (2, "mis"), (21, "mis"), (21, "nee"), (19, "mis"), (19, "pt"), (19, "nee")])
 def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     """Glass (scene 8: dispersive, wavelength termination), thin plastic (scene 10), plain Lambert (scene 0), rough clearcoat
     over rough metal (scene 17), rough SF11 glass (scene 11: microfacet reflection/transmission + light connection), smooth
     gold (scene 6), four instanced rough-gold heroes (scene 7: ConductorBsdf + complex Fresnel), SimplePbrMaterial with
     mixed metallic (scene 20, not a reference scene), point lights only (scenes 1, 2), spot + directional + area light
-    together (scene 21, not a reference scene)."""
+    together (scene 21, not a reference scene), environment light over SimplePbr / clearcoat / plastic heroes (scene 19)."""
     pair = {}
     for name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()
@@ -223,7 +223,7 @@ def test_cpp_host_cli_matches_python_binding(product, pkg, tmp_path):
         subprocess.check_call(["make", "-C", os.path.dirname(exe)])
     assets_dir = str(tmp_path / "assets")
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "export_assets.py"), assets_dir])
-    for scene_id, renderer in ((3, "mis"), (17, "nee"), (7, "mis"), (1, "nee")):
+    for scene_id, renderer in ((3, "mis"), (17, "nee"), (7, "mis"), (1, "nee"), (19, "mis")):
         out = str(tmp_path / f"cli_{scene_id}.png")
         env = dict(os.environ, MI355PT_ASSETS=assets_dir, MI355PT_DATA=os.path.join(root, "toy-cpu-pathtracing_amd", "data"))
         r = subprocess.run([exe, "--scene", str(scene_id), "--renderer", renderer, "--sampler", "sobol", "--spp", "8", "--width", "96",

@@ -162,6 +162,26 @@ def single_triangle():
     return dict(pos=pos, nrm=nrm, uv=uv, idx=np.array([[0, 1, 2]], dtype=np.uint32))
 
 
+def sky_envmap(w=128, h=64, seed=3):
+    """Synthetic lat-long HDR sky standing in for scene_19.rs's scythian_tombs_2_1k.exr (an LFS stub): blue-to-white sky
+    gradient, warm sun disc (~60x the sky), dim ground, mild seeded clouds.  Row 0 = +y pole, float32 (h, w, 3)."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(h, dtype=np.float64) + 0.5) / h
+    u = (np.arange(w, dtype=np.float64) + 0.5) / w
+    theta, phi = np.meshgrid(v * np.pi, u * 2 * np.pi, indexing="ij")
+    d = np.stack([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)], -1)
+    up = np.clip(d[..., 1], 0.0, 1.0)
+    sky = (1.0 - up[..., None]) * np.array([0.9, 0.95, 1.0]) + up[..., None] * np.array([0.25, 0.45, 0.9])
+    ground = np.array([0.12, 0.10, 0.08])
+    img = np.where(d[..., 1:2] >= 0.0, sky, ground)
+    sun_dir = np.array([0.5, 0.6, 0.62]); sun_dir /= np.linalg.norm(sun_dir)
+    c = np.clip(d @ sun_dir, -1.0, 1.0)
+    img = img + np.array([60.0, 52.0, 40.0]) * np.exp((c - 1.0) * 250.0)[..., None]
+    clouds = _value_noise(max(w, h), 4, rng)[:h, :w]
+    img = img * (0.85 + 0.3 * clouds[..., None])
+    return np.ascontiguousarray(img.astype(F))
+
+
 def _value_noise(n, octaves, rng):
     out = np.zeros((n, n))
     amp, tot = 1.0, 0.0

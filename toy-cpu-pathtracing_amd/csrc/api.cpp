@@ -278,6 +278,24 @@ int mi355pt_scene_add_delta_light(mi355pt_scene* s, const mi355pt_light_desc* d)
     im.delta_lights.push_back(hl);
     return MI355PT_OK;
 }
+int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const float* rgb, uint32_t w, uint32_t h, const float* l2w,
+                                        uint32_t illuminant_lut) {
+    if (!s || !rgb || !l2w || w == 0 || h == 0) return fail(MI355PT_E_INVALID, "bad environment light arguments");
+    SceneImpl& im = s->impl;
+    if (im.env.present) return fail(MI355PT_E_INVALID, "only one environment light per scene is supported on the device");
+    if (illuminant_lut >= im.luts.size()) return fail(MI355PT_E_INVALID, "bad illuminant LUT id");
+    im.env.present = true; im.env.intensity = intensity; im.env.w = w; im.env.h = h; im.env.illuminant_lut = illuminant_lut;
+    im.env.rgb.assign(rgb, rgb + (size_t)w * h * 3);
+    std::memcpy(im.env.l2w, l2w, sizeof(float) * 16);
+    DevMaterial m{};                         // hidden emissive material: the integrated RgbIlluminantSpectrum, filled in at build()
+    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.intensity = 1.0f; m.color.kind = SPK_CONSTANT;
+    im.materials.push_back(m);
+    mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE;
+    im.mat_descs.push_back(md);
+    mi355pt_light_desc ld{}; ld.kind = LK_ENV; ld.intensity = intensity; std::memcpy(ld.local_to_world, l2w, sizeof(float) * 16);
+    im.delta_lights.push_back(HostDeltaLight{ld, (uint32_t)im.materials.size() - 1, (uint32_t)im.instances.size()});
+    return MI355PT_OK;
+}
 int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, const float* l2w) {
     if (!s || !l2w) return fail(MI355PT_E_INVALID, "null argument");
     if (geom >= s->impl.meshes.size() || mat >= s->impl.materials.size()) return fail(MI355PT_E_INVALID, "bad geometry/material id");

@@ -70,7 +70,7 @@ struct alignas(16) DevInstance {
 };
 static_assert(sizeof(DevInstance) == 80, "instance record");
 
-enum : uint32_t { SPK_CONSTANT = 0, SPK_SIGMOID = 1, SPK_LUT = 2, SPK_TEXTURE = 3 };
+enum : uint32_t { SPK_CONSTANT = 0, SPK_SIGMOID = 1, SPK_LUT = 2, SPK_TEXTURE = 3, SPK_ILLUM = 4 };   // ILLUM: pad[0] = scale bits, id = illuminant LUT
 struct DevSpectrum {
     uint32_t kind;
     uint32_t id;       // LUT index or texture index
@@ -101,7 +101,7 @@ struct alignas(16) DevLightTri {
 };
 static_assert(sizeof(DevLightTri) == 48, "light tri");
 
-enum : uint32_t { LK_AREA = 0, LK_POINT = 1, LK_SPOT = 2, LK_DIRECTIONAL = 3 };
+enum : uint32_t { LK_AREA = 0, LK_POINT = 1, LK_SPOT = 2, LK_DIRECTIONAL = 3, LK_ENV = 4 };
 struct alignas(16) DevLight {
     uint32_t first_tri, n_tris;   // area: into light_tris
     uint32_t material;            // emissive material (delta lights: a hidden one holding the spectrum, intensity 1)
@@ -122,6 +122,19 @@ struct DevTexture {
     uint32_t w, h, pad;
 };
 
+// EnvironmentLight (primitive/impls/environment_light.rs): at most one per scene on the device
+struct DevEnv {
+    const float* texels;          // [h][w][4] float RGB0, row 0 = +y pole
+    const float* marginal;        // [h]
+    const float* conditional;     // [h][w]
+    uint32_t w, h;
+    float total_weight, intensity;
+    float l2r[9], r2l[9];         // linear parts, column-major 3x3
+    uint32_t illuminant_lut;      // presets::cie_illum_d6500()
+    uint32_t light_index;         // position in the light list
+    uint32_t present, pad;
+};
+
 struct DevScene {
     const DevNode* nodes;
     const DevTri* tris;
@@ -139,6 +152,7 @@ struct DevScene {
     uint32_t n_nodes, n_tris, n_lights, n_materials;
     int32_t root;                 // root link (node index, or leaf if the scene has <= MAX_LEAF_TRIS tris)
     uint32_t pad[3];
+    DevEnv env;
 };
 
 struct DevCamera {
@@ -161,7 +175,7 @@ struct DevParams {
 
 // Scene feature bits: the host picks the smallest kernel specialisation that covers the scene's materials, so a
 // Lambert-only Cornell box does not carry the registers and code of the clearcoat / dielectric / texture paths.
-enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_METAL = 32, FEAT_DELTA = 64, FEAT_ALL = 127 };
+enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_METAL = 32, FEAT_DELTA = 64, FEAT_ENV = 128, FEAT_ALL = 255 };
 
 struct DevStats {
     unsigned long long samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;

@@ -317,6 +317,7 @@ PT_DEV void eval_spectrum(const DevScene& sc, const DevSpectrum& sp, const Wl& w
         float v;
         if (kind == SPK_CONSTANT) v = c0;
         else if (kind == SPK_SIGMOID) v = sigmoid_value(c0, c1, c2, w.lam[i]);
+        else if (kind == SPK_ILLUM) v = __uint_as_float(sp.pad[0]) * sigmoid_value(c0, c1, c2, w.lam[i]) * lut_value(lut, w.lam[i]);   // rgb_illuminant_spectrum.rs:44-46
         else v = lut_value(lut, w.lam[i]);
         out[i] = (i > 0 && w.term) ? 0.0f : v;
     }

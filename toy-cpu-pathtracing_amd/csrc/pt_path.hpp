@@ -79,7 +79,72 @@ PT_DEV DevSpectrum load_spectrum(const DevSpectrum* p) {
     float4 a = q[0], b = q[1];
     DevSpectrum s;
     s.kind = __float_as_uint(a.x); s.id = __float_as_uint(a.y); s.c[0] = a.z; s.c[1] = a.w; s.c[2] = b.x;
+    s.pad[0] = __float_as_uint(b.y);
     return s;
+}
+
+// ---- EnvironmentLight (primitive/impls/environment_light.rs) ----
+PT_DEV void env_spherical(const DevScene& sc, f3 dir_render, float& theta, float& phi) {          // :96-103 after the rotation to local
+    f3 dl = mat3_mul(sc.env.r2l, dir_render);
+    theta = fminf(fmaxf(acosf(dl.y), 0.0f), PI_F);
+    phi = atan2f(dl.z, dl.x);
+    if (phi < 0.0f) phi += 2.0f * PI_F;
+}
+// direction_radiance (:292-305): bilinear texel -> RgbIlluminantSpectrum (scale * sigmoid * D65) -> * intensity
+PT_DEV void env_radiance(const DevScene& sc, f3 dir_render, const Wl& wl, float out[4]) {
+    float theta, phi;
+    env_spherical(sc, dir_render, theta, phi);
+    float u = fminf(fmaxf(phi / (2.0f * PI_F), 0.0f), 1.0f), v = fminf(fmaxf(theta / PI_F, 0.0f), 1.0f);
+    const uint32_t w = sc.env.w, h = sc.env.h;
+    float x = u * (float)(w - 1), y = v * (float)(h - 1);
+    uint32_t x0 = (uint32_t)floorf(x), y0 = (uint32_t)floorf(y);
+    uint32_t x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    float fx = x - (float)x0, fy = y - (float)y0;
+    const float4* t = (const float4*)sc.env.texels;
+    float4 p00 = t[(size_t)y0 * w + x0], p01 = t[(size_t)y0 * w + x1], p10 = t[(size_t)y1 * w + x0], p11 = t[(size_t)y1 * w + x1];
+    float rgb[3];
+    { float a = p00.x * (1.0f - fx) + p01.x * fx, b = p10.x * (1.0f - fx) + p11.x * fx; rgb[0] = a * (1.0f - fy) + b * fy; }
+    { float a = p00.y * (1.0f - fx) + p01.y * fx, b = p10.y * (1.0f - fx) + p11.y * fx; rgb[1] = a * (1.0f - fy) + b * fy; }
+    { float a = p00.z * (1.0f - fx) + p01.z * fx, b = p10.z * (1.0f - fx) + p11.z * fx; rgb[2] = a * (1.0f - fy) + b * fy; }
+    float scale = 2.0f * fmaxf(rgb[0], fmaxf(rgb[1], rgb[2]));                                     // rgb_illuminant_spectrum.rs:26-41
+    if (scale == 0.0f) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }                        // black texel: 0 (the reference divides 0/0)
+    float enc[3] = {rgb[0] / scale, rgb[1] / scale, rgb[2] / scale}, c[3];
+    rgb2spec_lookup(sc, enc, c);
+    const float* lut = sc.luts + (size_t)sc.env.illuminant_lut * 470;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float val = (scale * sigmoid_value(c[0], c[1], c[2], wl.lam[i])) * lut_value(lut, wl.lam[i]);
+        out[i] = ((i > 0 && wl.term) ? 0.0f : val) * sc.env.intensity;
+    }
+}
+PT_DEV float env_pdf(const DevScene& sc, f3 dir_render) {                                          // calculate_direction_pdf :212-238
+    if (!(sc.env.total_weight > 0.0f)) return 0.0f;
+    float theta, phi;
+    env_spherical(sc, dir_render, theta, phi);
+    const uint32_t w = sc.env.w, h = sc.env.h;
+    float u = phi / (2.0f * PI_F), v = theta / PI_F;
+    uint32_t x = min((uint32_t)floorf(u * (float)w), w - 1), y = min((uint32_t)floorf(v * (float)h), h - 1);
+    float4 p = ((const float4*)sc.env.texels)[(size_t)y * w + x];
+    float lum = 0.299f * p.x + 0.587f * p.y + 0.114f * p.z;
+    float st = fmaxf(sinf(theta), 1e-8f);
+    float pdf_tex = (lum * st) / sc.env.total_weight;
+    float jac = (float)w * (float)h / (2.0f * PI_F * PI_F * st);
+    return pdf_tex * jac;
+}
+PT_DEV uint32_t env_sample_cdf(const float* cdf, uint32_t n, float u) {                            // binary_search_by insertion point (:201-206)
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (cdf[mid] < u) lo = mid + 1; else hi = mid; }
+    return min(lo, n - 1);
+}
+PT_DEV void env_sample(const DevScene& sc, f2 uv, f3& wi, float& pdf_dir) {                        // sample_infinite_light :317-340
+    const uint32_t w = sc.env.w, h = sc.env.h;
+    uint32_t y = env_sample_cdf(sc.env.marginal, h, uv.x);
+    uint32_t x = env_sample_cdf(sc.env.conditional + (size_t)y * w, w, uv.y);
+    float u = ((float)x + 0.5f) / (float)w, v = ((float)y + 0.5f) / (float)h;
+    float theta = v * PI_F, phi = u * 2.0f * PI_F;
+    f3 wl = mk3(sinf(theta) * cosf(phi), cosf(theta), sinf(theta) * sinf(phi));
+    wi = mat3_mul(sc.env.l2r, wl);
+    pdf_dir = env_pdf(sc, wi);
 }
 
 PT_DEV float balance_heuristic(float a, float b) { return (a == 0.0f && b == 0.0f) ? 0.0f : a / (a + b); }   // common.rs:15-20
@@ -164,7 +229,26 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
     do_shadow = false;
 
     if (!got) {
-        end_path = true;   // no infinite lights in scope: radiance 0 (base_renderer.rs:180-186,240-253)
+        end_path = true;
+        if ((FEAT & FEAT_ENV) && sc.env.present) {
+            float rad[4];
+            env_radiance(sc, rd, wl, rad);
+            if (from_camera) {                                               // base_renderer.rs:180-187
+#pragma unroll
+                for (int i = 0; i < 4; ++i) L[i] = L[i] + T[i] * rad[i];
+            } else if (prm.strategy == 0u) {                                 // pt_renderer.rs:50-82: T * f * Le / pdf
+#pragma unroll
+                for (int i = 0; i < 4; ++i) L[i] = L[i] + sdiv((T[i] * pf[i]) * rad[i], p_pdf);
+            } else if (prm.strategy == 2u) {                                 // mis_renderer.rs:183-230 (also for specular samples)
+                // pdf_infinite_light_sample: probability among the INFINITE lights (1 with one environment light whose
+                // weight is non-zero, light_sampler.rs:115-153) times the direction pdf
+                float light_pdf = 1.0f * env_pdf(sc, rd);
+                float w = balance_heuristic(p_pdf, light_pdf);
+                float tf = 1.0f / p_pdf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) L[i] = L[i] + ((((T[i] * pf[i]) * rad[i]) * tf) * w);
+            }                                                                // nee_renderer.rs:139-153: nothing
+        }
     } else {
         Surface sf = load_surface(sc, hit);
         const DevMaterial* mat = sc.materials + sf.material;
@@ -627,7 +711,12 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     f3 dv, wi_r, ln = mk3(0, 0, 1);
                     float pdf_a = 1.0f, pdf_dir = 0.0f;
                     float dl_scale = 1.0f;                                      // delta lights: falloff
-                    if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
+                    float env_rad[4] = {0, 0, 0, 0};
+                    if ((FEAT & FEAT_ENV) && lt.kind == LK_ENV) {               // sample_infinite_light (environment_light.rs:317-340)
+                        env_sample(sc, luv, wi_r, pdf_dir);
+                        dv = wi_r;
+                        env_radiance(sc, wi_r, wl, env_rad);
+                    } else if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
                         // Scene::calculate_light for PrimitiveDelta{Point,Directional}Light (scene.rs:114-139)
                         if (lt.kind == LK_DIRECTIONAL) {                        // directional_light.rs:95-107
                             dv = mk3(lt.pos[0], lt.pos[1], lt.pos[2]);
@@ -753,7 +842,12 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     }
                     float dist2 = dot(dv, dv);
                     do_shadow = true;
-                    if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
+                    if ((FEAT & FEAT_ENV) && lt.kind == LK_ENV) {               // evaluate_infinite_light{,_with_mis} (common.rs:174-241)
+                        float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
+                        sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = 3.402823466e+38f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sh_c[i] = (T[i] * sdiv(fl[i] * env_rad[i], pdf_dir * lprob)) * wgt;
+                    } else if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
                         // evaluate_delta_{point,directional}_light (common.rs:23-79): no MIS weight
                         if (lt.kind == LK_DIRECTIONAL) {
                             sh_d = dv; sh_o = sf.p; sh_t = 3.402823466e+38f;      // the ray is not moved forward (:60-61)

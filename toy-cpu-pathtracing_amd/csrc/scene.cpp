@@ -138,6 +138,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
 
     // delta lights enter the light list in creation order, interleaved with the emissive instances
     size_t next_delta = 0;
+    uint32_t env_light_index = 0;
+    float env_l2r[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     float sb_lo[3] = {INFINITY, INFINITY, INFINITY}, sb_hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // scene bounds (render space)
     auto push_delta = [&](const HostDeltaLight& hl) {
         DevLight dl{};
@@ -145,6 +147,13 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         dl.intensity = hl.d.intensity; dl.angle_inner = hl.d.angle_inner; dl.angle_outer = hl.d.angle_outer;
         float l2r[16];
         mat4_mul(w2r, hl.d.local_to_world, l2r);
+        if (hl.d.kind == LK_ENV) {                                              // EnvironmentLight: phi = intensity * integrated spectrum
+            dl.area_sum = hl.d.intensity;
+            env_light_index = (uint32_t)lights.size();
+            std::memcpy(env_l2r, l2r, sizeof(env_l2r));
+            lights.push_back(dl);
+            return;
+        }
         if (hl.d.kind == MI355PT_LIGHT_DIRECTIONAL) {
             V3 d = normalize(V3{l2r[8], l2r[9], l2r[10]});                        // local_to_render * (0,0,1), normalised
             dl.pos[0] = d.x; dl.pos[1] = d.y; dl.pos[2] = d.z;
@@ -293,6 +302,61 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         for (size_t i = 0; i < n; ++i) texels.push_back((uint32_t)t.rgb[3 * i] | ((uint32_t)t.rgb[3 * i + 1] << 8) | ((uint32_t)t.rgb[3 * i + 2] << 16));
     }
 
+    // EnvironmentLight::new (environment_light.rs:28-75) + build_2d_cdf (:153-199)
+    std::vector<float> env_texels, env_marginal, env_conditional;
+    DevEnv denv{};
+    if (env.present) {
+        if (table.empty()) { *err = "environment light needs the rgb2spec table"; return MI355PT_E_INVALID; }
+        const uint32_t w = env.w, h = env.h;
+        float tot[3] = {0, 0, 0};
+        env_texels.resize((size_t)w * h * 4);
+        for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) {
+            const float* p = &env.rgb[((size_t)y * w + x) * 3];
+            for (int c = 0; c < 3; ++c) { tot[c] += p[c]; env_texels[((size_t)y * w + x) * 4 + c] = p[c]; }
+            env_texels[((size_t)y * w + x) * 4 + 3] = 0.0f;
+        }
+        float n = (float)(w * h);
+        for (int c = 0; c < 3; ++c) tot[c] /= n;
+        DevMaterial& hm = materials[lights[env_light_index].material];     // integrated RgbIlluminantSpectrum (rgb_illuminant_spectrum.rs:26-41)
+        float scale = 2.0f * std::fmax(tot[0], std::fmax(tot[1], tot[2]));
+        if (scale == 0.0f) { hm.color.kind = SPK_CONSTANT; hm.color.c[0] = 0.0f; }
+        else {
+            float enc[3] = {tot[0] / scale, tot[1] / scale, tot[2] / scale};
+            hm.color.kind = SPK_ILLUM; hm.color.id = env.illuminant_lut;
+            if (!table_lookup_srgb(enc, hm.color.c)) { *err = "rgb2spec lookup failed"; return MI355PT_E_INVALID; }
+            std::memcpy(&hm.color.pad[0], &scale, sizeof(float));
+        }
+        const float PI_F = 3.14159265358979323846f;
+        std::vector<float> row_w(h, 0.0f);
+        env_conditional.assign((size_t)w * h, 0.0f); env_marginal.assign(h, 0.0f);
+        for (uint32_t y = 0; y < h; ++y) {
+            float row_sum = 0.0f;
+            for (uint32_t x = 0; x < w; ++x) {
+                float v = ((float)y + 0.5f) / (float)h;
+                float theta = v * PI_F;
+                const float* p = &env.rgb[((size_t)y * w + x) * 3];
+                float lum = 0.299f * p[0] + 0.587f * p[1] + 0.114f * p[2];
+                row_sum += lum * std::fmax(std::sin(theta), 1e-8f);
+                env_conditional[(size_t)y * w + x] = row_sum;
+            }
+            row_w[y] = row_sum;
+            if (row_sum > 0.0f) for (uint32_t x = 0; x < w; ++x) env_conditional[(size_t)y * w + x] /= row_sum;
+        }
+        float total = 0.0f;
+        for (float r : row_w) total += r;
+        float cum = 0.0f;
+        for (uint32_t y = 0; y < h; ++y) { cum += row_w[y]; env_marginal[y] = total > 0.0f ? cum / total : (float)(y + 1) / (float)h; }
+        denv.w = w; denv.h = h; denv.total_weight = total; denv.intensity = env.intensity; denv.illuminant_lut = env.illuminant_lut;
+        denv.light_index = env_light_index; denv.present = 1;
+        double a[9] = {env_l2r[0], env_l2r[1], env_l2r[2], env_l2r[4], env_l2r[5], env_l2r[6], env_l2r[8], env_l2r[9], env_l2r[10]};
+        for (int i = 0; i < 9; ++i) denv.l2r[i] = (float)a[i];
+        double det = a[0] * (a[4] * a[8] - a[7] * a[5]) - a[3] * (a[1] * a[8] - a[7] * a[2]) + a[6] * (a[1] * a[5] - a[4] * a[2]);
+        double inv[9] = {(a[4] * a[8] - a[7] * a[5]) / det, -(a[1] * a[8] - a[7] * a[2]) / det, (a[1] * a[5] - a[4] * a[2]) / det,
+                         -(a[3] * a[8] - a[6] * a[5]) / det, (a[0] * a[8] - a[6] * a[2]) / det, -(a[0] * a[5] - a[3] * a[2]) / det,
+                         (a[3] * a[7] - a[6] * a[4]) / det, -(a[0] * a[7] - a[6] * a[1]) / det, (a[0] * a[4] - a[3] * a[1]) / det};
+        for (int i = 0; i < 9; ++i) denv.r2l[i] = (float)inv[i];
+    }
+
     int rc;
     std::memset(&dev, 0, sizeof(dev));
     if ((rc = upload(this, bvh.nodes, &dev.nodes, err))) return rc;
@@ -308,11 +372,18 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     if ((rc = upload(this, znodes, &dev.z_nodes, err))) return rc;
     if ((rc = upload(this, texels, &dev.texels, err))) return rc;
     if ((rc = upload(this, dtex, &dev.textures, err))) return rc;
+    if (env.present) {
+        if ((rc = upload(this, env_texels, &denv.texels, err))) return rc;
+        if ((rc = upload(this, env_marginal, &denv.marginal, err))) return rc;
+        if ((rc = upload(this, env_conditional, &denv.conditional, err))) return rc;
+    }
+    dev.env = denv;
     dev.n_nodes = (uint32_t)bvh.nodes.size(); dev.n_tris = (uint32_t)tris.size();
     dev.n_lights = (uint32_t)lights.size(); dev.n_materials = (uint32_t)materials.size();
     dev.root = bvh.root;
     features = lights.size() == 1 ? 0u : FEAT_MLIGHT;
     if (!delta_lights.empty()) features |= FEAT_DELTA;
+    if (env.present) features |= FEAT_ENV;
     for (const HostInstance& inst : instances) {
         const DevMaterial& m = materials[inst.mat];
         if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | (m.roughness >= 1e-3f ? FEAT_ROUGH : 0u);

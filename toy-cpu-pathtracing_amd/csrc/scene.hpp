@@ -43,6 +43,7 @@ struct SceneImpl {
     std::vector<mi355pt_material_desc> mat_descs;
     std::vector<DevMaterial> materials;
     std::vector<HostInstance> instances;
+    struct HostEnv { float intensity = 1.0f; uint32_t w = 0, h = 0, illuminant_lut = 0; std::vector<float> rgb; float l2w[16]; bool present = false; } env;
     std::vector<HostDeltaLight> delta_lights;   // creation order; after_instances = instances.size() at creation (light_sampler.rs:163-180)
     // ---- lowered ----
     bool built = false;

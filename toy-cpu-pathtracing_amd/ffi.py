@@ -99,7 +99,7 @@ def _ptr(a, ty):
 # every symbol include/mi355pt.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
-    "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_build", "render", "render_accum_device", "film_resolve_device",
+    "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_build", "render", "render_accum_device", "film_resolve_device",
     "quantize_u8", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "last_error", "version",
 ]
 
@@ -119,6 +119,8 @@ class Backend:
         f("scene_add_material").argtypes = [C.c_void_p, C.POINTER(MaterialDesc), C.POINTER(C.c_uint32)]
         f("scene_add_instance").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         f("scene_add_delta_light").argtypes = [C.c_void_p, C.POINTER(LightDesc)]
+        f("scene_add_environment_light").argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
+                                                     C.c_uint32]
         f("scene_build").argtypes = [C.c_void_p, C.POINTER(Camera)]
         f("probe_sobol").argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32)]
         f("probe_intersect").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float),
@@ -225,6 +227,14 @@ class SceneHandle:
         d.spectrum = spectrum
         d.local_to_world = (C.c_float * 16)(*np.ascontiguousarray(m.T.reshape(-1)))   # column-major
         self.b.check(self.b.fn("scene_add_delta_light")(self.h, C.byref(d)), "scene_add_delta_light")
+
+    def add_environment_light(self, intensity, rgb, illuminant_lut, local_to_world=None):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        m = np.eye(4, dtype=np.float32) if local_to_world is None else np.asarray(local_to_world, dtype=np.float32)
+        cols = np.ascontiguousarray(m.T.reshape(-1))
+        self.b.check(self.b.fn("scene_add_environment_light")(self.h, intensity, _ptr(rgb, C.c_float), rgb.shape[1], rgb.shape[0],
+                                                              _ptr(cols, C.c_float), illuminant_lut), "scene_add_environment_light")
 
     def build(self, cam):
         self.b.check(self.b.fn("scene_build")(self.h, C.byref(cam)), "scene_build")

@@ -53,7 +53,8 @@ int main(int argc, char** argv) {
             case 8: load_scene_8(scene, camera); break;
             case 10: load_scene_10(scene, camera); break;
             case 17: load_scene_17(scene, camera); break;
-            default: std::fprintf(stderr, "scene %u is outside the MI355X hot-path scope (scenes 0, 1, 2, 3, 6, 7, 8, 10, 11, 17)\n", a.scene); return 2;
+            case 19: load_scene_19(scene, camera); break;
+            default: std::fprintf(stderr, "scene %u is outside the MI355X hot-path scope (scenes 0, 1, 2, 3, 6, 7, 8, 10, 11, 17, 19)\n", a.scene); return 2;
         }
         std::puts("Start build scene.");                                                // main.rs:103-109
         auto t0 = std::chrono::steady_clock::now();

@@ -273,6 +273,21 @@ inline ImageRgb8 load_png(const std::string& path) {
     }
     return im;
 }
+// float RGB environment maps: PFM ("PF", little or big endian, rows bottom-to-top) -> top-to-bottom h*w*3
+inline std::vector<float> load_pfm(const std::string& path, uint32_t* w, uint32_t* h) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open environment map " + path);
+    std::string magic; float scale;
+    f >> magic >> *w >> *h >> scale; f.get();
+    if (magic != "PF" || !*w || !*h) throw std::runtime_error(path + ": expected a colour PFM (PF)");
+    std::vector<float> raw((size_t)*w * *h * 3);
+    f.read((char*)raw.data(), (std::streamsize)(raw.size() * sizeof(float)));
+    if (!f) throw std::runtime_error(path + ": truncated");
+    if (scale > 0.0f) for (float& v : raw) { uint32_t u; std::memcpy(&u, &v, 4); u = __builtin_bswap32(u); std::memcpy(&v, &u, 4); }   // big endian
+    std::vector<float> out(raw.size());
+    for (uint32_t y = 0; y < *h; ++y) std::memcpy(&out[(size_t)y * *w * 3], &raw[(size_t)(*h - 1 - y) * *w * 3], (size_t)*w * 3 * sizeof(float));
+    return out;
+}
 inline ImageRgb8 load_image(const std::string& path) {      // by extension: .png like the reference's assets, .ppm for the synthetic stand-ins
     return path.size() >= 4 && path.compare(path.size() - 4, 4, ".png") == 0 ? load_png(path) : load_ppm(path);
 }
@@ -467,6 +482,7 @@ struct GeometryPrimitive { GeometryIndex geometry_index; Material surface_materi
 // CreatePrimitiveDesc::{SingleTriangle,PointLight,SpotLight,DirectionalLight}Primitive (primitive/create_desc.rs:17-66)
 struct SingleTrianglePrimitive { Vec3 positions[3]; Vec3 normals[3]; float uvs[3][2]; Material surface_material; Transform transform; };
 struct PointLightPrimitive { float intensity; Spectrum spectrum; Transform transform; };
+struct EnvironmentLightPrimitive { float intensity; std::string texture_path; Transform transform; };   // .pfm here (the reference: .exr)
 struct SpotLightPrimitive { float angle_inner, angle_outer, intensity; Spectrum spectrum; Transform transform; };
 struct DirectionalLightPrimitive { float intensity; Spectrum spectrum; Transform transform; };
 
@@ -518,6 +534,12 @@ public:
         uint32_t id;
         check(mi355pt_scene_add_mesh(s_, m.pos.data(), m.nrm.data(), m.uv.data(), m.tangent.data(), m.idx.data(), 3, 1, &id), "mi355pt_scene_add_mesh");
         create_primitive(GeometryPrimitive{{id}, d.surface_material, d.transform});
+    }
+    void create_primitive(const EnvironmentLightPrimitive& d) {
+        uint32_t w = 0, h = 0;
+        std::vector<float> rgb = load_pfm(d.texture_path, &w, &h);
+        mi355pt_spectrum d65 = lower_spectrum(presets::cie_illum_d6500());       // rgb_illuminant_spectrum.rs:28
+        check(mi355pt_scene_add_environment_light(s_, d.intensity, rgb.data(), w, h, d.transform.m, d65.id), "mi355pt_scene_add_environment_light");
     }
     void create_primitive(const PointLightPrimitive& d) { add_light(MI355PT_LIGHT_POINT, d.intensity, 0, 0, d.spectrum, d.transform); }
     void create_primitive(const SpotLightPrimitive& d) { add_light(MI355PT_LIGHT_SPOT, d.intensity, d.angle_inner, d.angle_outer, d.spectrum, d.transform); }

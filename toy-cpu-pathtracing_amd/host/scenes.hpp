@@ -1,4 +1,4 @@
-// load_scene_N(&mut scene, &mut camera) of renderer/src/scene/scene_{0,1,2,3,6,7,8,10,11,17}.rs, call for call.
+// load_scene_N(&mut scene, &mut camera) of renderer/src/scene/scene_{0,1,2,3,6,7,8,10,11,17,19}.rs, call for call.
 // Asset paths keep the reference's names under $MI355PT_ASSETS (default ./assets); the files are the synthetic
 // stand-ins written by tools/export_assets.py (the reference's are git-LFS stubs), textures as binary PPM.
 #pragma once
@@ -71,6 +71,29 @@ inline void load_scene_2(Scene& scene, Camera& camera) {            // scene_2.r
     load_room(scene, false);
     scene.create_primitive(PointLightPrimitive{10.0f, presets::cie_illum_d6500(), Transform::from_translate({0.0f, 3.0f, 0.0f})});
     camera.set_look_to({0.0f, 3.5f, 6.0f}, {0.0f, -1.0f, -3.0f}, {0.0f, 1.0f, 0.0f});
+}
+inline void load_scene_19(Scene& scene, Camera& camera) {           // scene_19.rs:17-153: three heroes under an environment light
+    // stand-ins: constant metallic / roughness instead of the FloatTexture maps, sRGB-encoded plastic colour, PFM sky
+    GeometryIndex floor_geom = scene.load_obj(asset("yuka.obj"));
+    scene.create_primitive(GeometryPrimitive{floor_geom, LambertMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.8f, 0.8f, 0.8f})), NormalParameter::none()),
+                                             Transform::identity()});
+    GeometryIndex dragon_geom = scene.load_obj(asset("dragon.min.obj"));
+    scene.create_primitive(GeometryPrimitive{dragon_geom,
+                                             SimplePbrMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.8f, 0.6f, 0.3f})), FloatParameter::constant(0.5f),
+                                                                       FloatParameter::constant(0.4f), NormalParameter::none(), FloatParameter::constant(1.5f)),
+                                             Transform::identity()});
+    scene.create_primitive(GeometryPrimitive{
+        dragon_geom,
+        SimpleClearcoatPbrMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.8f, 0.8f, 0.8f})), FloatParameter::constant(1.0f), FloatParameter::constant(0.7f),
+                                           NormalParameter::none(), FloatParameter::constant(1.5f), FloatParameter::constant(1.5f), FloatParameter::constant(0.01f),
+                                           SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.7f, 0.8f, 1.0f})), FloatParameter::constant(0.8f)),
+        Transform::identity().translate({0.5f, 0.0f, 0.5f})});
+    scene.create_primitive(GeometryPrimitive{dragon_geom,
+                                             PlasticMaterial::create(1.5f, SpectrumParameter::constant(RgbAlbedoSpectrum::create({0.66f, 0.95f, 1.0f})), NormalParameter::none(), false,
+                                                                     FloatParameter::constant(0.0f)),
+                                             Transform::identity().translate({-0.5f, 0.0f, -0.5f})});
+    scene.create_primitive(EnvironmentLightPrimitive{1.0f, asset("sky/scythian_tombs_2_1k.pfm"), Transform::identity()});
+    camera.set_look_to({-1.5f, 0.8f, 2.5f}, {1.5f, -0.4f, -2.5f}, {0.0f, 1.0f, 0.0f});
 }
 inline void load_scene_6(Scene& scene, Camera& camera) {            // scene_6.rs:13-110: smooth gold hero
     GeometryIndex geom = scene.load_obj(asset("bunny.obj"));

@@ -160,6 +160,23 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         _room(scene, p, with_light=False)
         scene.add_delta_light(LIGHT_POINT, 10.0, Spectrum.lut(scene.add_lut470(p["cie_illum_d6500"])), _translate(0.0, 3.0, 0.0))
         cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 19:   # scene_19.rs:17-153: floor + three heroes (SimplePbr, clearcoat, plastic) under an environment light.
+        # Stand-ins: constant metallic/roughness instead of FloatTexture maps, sRGB-encoded plastic colour, synthetic sky.
+        room = _asset("room")
+        scene.add_instance(scene.add_mesh(room["yuka"]), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        g = scene.add_mesh(_asset("dragon"))
+        d = MaterialDesc(); d.type = MAT_SIMPLE_PBR; d.color = Spectrum.rgb_albedo_srgb(0.8, 0.6, 0.3)
+        d.metallic = 0.5; d.roughness = 0.4; d.normal_tex = NONE; d.ior = 1.5
+        scene.add_instance(g, scene.add_material(d))
+        d = MaterialDesc(); d.type = MAT_CLEARCOAT; d.color = Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8)
+        d.metallic = 1.0; d.roughness = 0.7; d.normal_tex = NONE; d.ior = 1.5; d.clearcoat_ior = 1.5
+        d.clearcoat_roughness = 0.01; d.clearcoat_tint = Spectrum.rgb_albedo_srgb(0.7, 0.8, 1.0); d.clearcoat_thickness = 0.8
+        scene.add_instance(g, scene.add_material(d), _translate(0.5, 0.0, 0.5))
+        d = MaterialDesc(); d.type = MAT_PLASTIC; d.eta = Spectrum.constant(1.5); d.color = Spectrum.rgb_albedo_srgb(0.66, 0.95, 1.0)
+        d.normal_tex = NONE; d.thin = 0; d.roughness = 0.0
+        scene.add_instance(g, scene.add_material(d), _translate(-0.5, 0.0, -0.5))
+        scene.add_environment_light(1.0, assets.sky_envmap(), scene.add_lut470(p["cie_illum_d6500"]))
+        cam = make_camera((-1.5, 0.8, 2.5), (1.5, -0.4, -2.5), (0.0, 1.0, 0.0), width, height)
     elif scene_id == 21:   # not a reference scene: scene 2's room lit by a spot light, a directional light AND the area light
         g = scene.add_mesh(_asset("bunny"))
         scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
