@@ -501,8 +501,17 @@ PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* s
 // fetches the owner's ray with ds_bpermute and runs the same intersect_triangle().  Any-hit results are order independent
 // (exists a hit in (0, t_max]), so the outcome is identical to trace_any; an occluded lane stops at the next flush.
 constexpr uint32_t ANY_RING = 256;            // entries; a step appends <= 2 per lane, a flush leaves < 64 behind
-struct AnyLds { uint32_t* ring; uint32_t* occl; };   // ring[ANY_RING] (tri | owner << 26), occl[2] (bit per lane)
+struct AnyLds { uint32_t* ring; uint32_t* occl; uint32_t* pair; };   // ring[ANY_RING] (tri | owner << 26), occl[2] (bit per lane), pair[64] (steal rounds)
 
+#ifndef PT_ANY_STEAL
+#define PT_ANY_STEAL 1        // idle lanes take whole subtrees off the stacks of the lanes still walking (same ray, same result)
+#endif
+#ifndef PT_STEAL_EVERY
+#define PT_STEAL_EVERY 1u
+#endif
+#ifndef PT_STEAL_MAX_ACTIVE
+#define PT_STEAL_MAX_ACTIVE 52
+#endif
 template <bool STATS>
 PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bool want, uint32_t* stack, uint32_t lane, const AnyLds& L,
                                StatCounters& st) {
@@ -511,32 +520,35 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
     const uint32_t kpack = (uint32_t)rs.kx | ((uint32_t)rs.ky << 2) | ((uint32_t)rs.kz << 4);
     if (lane < 2) L.occl[lane] = 0u;
     __syncthreads();
-    int sp = 0;
+    // the ray this lane is WALKING (its own, or one it is helping with) — the lane's own ray stays in ro/rd/rs for the flushes
+    f3 w_ro = ro, w_inv = rs.inv; float w_tmax = t_max; uint32_t owner = lane;
+    int sp = 0, sb = 0;                       // this lane's LDS stack holds [sb, sp): pops come off the top, steals off the bottom
     int32_t cur = sc.root;
     uint32_t leaf_off = 0;                    // triangles of the current leaf already queued
     bool done = !want;
     uint32_t head = 0, tail = 0;              // wave-uniform ring cursors
+    uint32_t since_steal = 0;
     if (STATS && want) st.shadow_rays++;
 
     auto flush = [&](uint32_t n) {            // test ring entries [head, head + n), n <= 64
         const bool valid = lane < n;
         const uint32_t e = valid ? L.ring[(head + lane) & (ANY_RING - 1u)] : (lane << 26);
-        const uint32_t owner = e >> 26, tri = e & 0x03ffffffu;
-        f3 o2 = mk3(__shfl(ro.x, owner), __shfl(ro.y, owner), __shfl(ro.z, owner));
-        f3 d2 = mk3(__shfl(rd.x, owner), __shfl(rd.y, owner), __shfl(rd.z, owner));
-        float tm = __shfl(t_max, owner);
-        uint32_t kp = __shfl(kpack, owner);
-        float sx = __shfl(rs.sx, owner), sy = __shfl(rs.sy, owner), sz = __shfl(rs.sz, owner);
+        const uint32_t own = e >> 26, tri = e & 0x03ffffffu;
+        f3 o2 = mk3(__shfl(ro.x, own), __shfl(ro.y, own), __shfl(ro.z, own));
+        f3 d2 = mk3(__shfl(rd.x, own), __shfl(rd.y, own), __shfl(rd.z, own));
+        float tm = __shfl(t_max, own);
+        uint32_t kp = __shfl(kpack, own);
+        float sx = __shfl(rs.sx, own), sy = __shfl(rs.sy, own), sz = __shfl(rs.sz, own);
         if (valid) {
             TriVerts tv = load_tri(sc.tris, tri);
             float t, b0, b1, b2;
             if (STATS) { st.tris_shadow++; if (wave_leader()) st.w[3]++; }
             if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, tm, tv, t, b0, b1, b2))
-                atomicOr(&L.occl[owner >> 5], 1u << (owner & 31u));
+                atomicOr(&L.occl[own >> 5], 1u << (own & 31u));
         }
         head += n;
         __syncthreads();
-        if ((L.occl[lane >> 5] >> (lane & 31u)) & 1u) done = true;    // early out for lanes found occluded
+        if ((L.occl[owner >> 5] >> (owner & 31u)) & 1u) done = true;  // early out: the ray this lane walks is already occluded
     };
 
     for (;;) {
@@ -545,21 +557,21 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
             float4 nx = q[0], ny = q[1], nz = q[2];
             int2 ch = *(const int2*)(q + 3);
             if (STATS) { st.nodes_shadow++; if (wave_leader()) st.w[2]++; }
-            float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
-            float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
-            float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
-            float l1y = (ny.y - ro.y) * rs.inv.y, h1y = (ny.w - ro.y) * rs.inv.y;
-            float l0z = (nz.x - ro.z) * rs.inv.z, h0z = (nz.z - ro.z) * rs.inv.z;
-            float l1z = (nz.y - ro.z) * rs.inv.z, h1z = (nz.w - ro.z) * rs.inv.z;
+            float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
+            float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
+            float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;
+            float l1y = (ny.y - w_ro.y) * w_inv.y, h1y = (ny.w - w_ro.y) * w_inv.y;
+            float l0z = (nz.x - w_ro.z) * w_inv.z, h0z = (nz.z - w_ro.z) * w_inv.z;
+            float l1z = (nz.y - w_ro.z) * w_inv.z, h1z = (nz.w - w_ro.z) * w_inv.z;
             float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
-            float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_max));
+            float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), w_tmax));
             float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
-            float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_max));
+            float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), w_tmax));
             bool hit0 = n0 <= f0, hit1 = n1 <= f1;
             if (hit0 && hit1) { stack[sp * 64] = (uint32_t)ch.y; ++sp; cur = ch.x; }
             else if (hit0) cur = ch.x;
             else if (hit1) cur = ch.y;
-            else if (sp == 0) done = true;
+            else if (sp == sb) done = true;
             else { --sp; cur = (int32_t)stack[sp * 64]; }
         }
         // lanes sitting in a leaf queue up to two of its triangles per step, then move on
@@ -572,20 +584,193 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
             const unsigned long long m2 = __ballot(a == 2u);
             const unsigned long long below = (1ull << lane) - 1ull;
             const uint32_t pos = tail + (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
-            if (a >= 1u) L.ring[pos & (ANY_RING - 1u)] = first | (lane << 26);
-            if (a == 2u) L.ring[(pos + 1u) & (ANY_RING - 1u)] = (first + 1u) | (lane << 26);
+            if (a >= 1u) L.ring[pos & (ANY_RING - 1u)] = first | (owner << 26);
+            if (a == 2u) L.ring[(pos + 1u) & (ANY_RING - 1u)] = (first + 1u) | (owner << 26);
             tail += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
             if (at_leaf) {
                 if (rem > 2u) leaf_off += 2u;
-                else { leaf_off = 0u; if (sp == 0) done = true; else { --sp; cur = (int32_t)stack[sp * 64]; } }
+                else { leaf_off = 0u; if (sp == sb) done = true; else { --sp; cur = (int32_t)stack[sp * 64]; } }
             }
             __syncthreads();
             while (tail - head >= 64u) flush(64u);
         }
-        if (__ballot(!done) == 0ull) break;
+        const unsigned long long m_act = __ballot(!done);
+        if (m_act == 0ull) break;
+#if PT_ANY_STEAL
+        // work stealing: when most of the wave idles, idle lanes take the BOTTOM stack entry (the largest pending subtree) of
+        // lanes that still have one, together with that lane's working ray.  Any-hit is an OR over all subtrees, so the
+        // result is unchanged; the owner's bit in occl[] is shared by everybody working on the ray.
+        if (++since_steal >= PT_STEAL_EVERY && __popcll(m_act) <= PT_STEAL_MAX_ACTIVE) {
+            const unsigned long long m_donor = __ballot(!done && sp > sb);
+            if (m_donor != 0ull) {
+                since_steal = 0u;
+                const unsigned long long m_idle = ~m_act;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t n_pairs = min((uint32_t)__popcll(m_donor), (uint32_t)__popcll(m_idle));
+                const bool donor = !done && sp > sb;
+                const uint32_t rank = (uint32_t)__popcll((donor ? m_donor : m_idle) & below);
+                if (donor && rank < n_pairs) L.pair[rank] = lane;
+                __syncthreads();
+                const bool taker = done && rank < n_pairs;
+                const uint32_t from = taker ? L.pair[rank] : lane;
+                // every lane reads its partner's state (shuffles are wave-wide); only takers keep it
+                const int d_sb = __shfl(sb, from);
+                const float rx = __shfl(w_ro.x, from), ry = __shfl(w_ro.y, from), rz = __shfl(w_ro.z, from);
+                const float ix = __shfl(w_inv.x, from), iy = __shfl(w_inv.y, from), iz = __shfl(w_inv.z, from);
+                const float tm = __shfl(w_tmax, from);
+                const uint32_t ow = __shfl(owner, from);
+                if (taker) {
+                    cur = (int32_t)(stack - lane)[d_sb * 64 + from];      // the donor's bottom entry
+                    w_ro = mk3(rx, ry, rz); w_inv = mk3(ix, iy, iz); w_tmax = tm; owner = ow;
+                    sp = sb = 0; leaf_off = 0u; done = false;
+                }
+                if (donor && rank < n_pairs) ++sb;
+                __syncthreads();
+            }
+        }
+#endif
     }
     if (tail != head) flush(tail - head);     // stragglers' last pairs (tail - head < 64 here)
     return ((L.occl[lane >> 5] >> (lane & 31u)) & 1u) != 0u;
+}
+
+// Closest hit, wave-cooperative: the same three ideas as trace_any_deferred — lanes only walk nodes (near child first,
+// pruned by the best distance known for the ray they walk), queue (triangle, owner) pairs, the wave tests the queue densely,
+// and idle lanes steal whole subtrees from the bottom of busy lanes' stacks.  Results are merged per ray with an LDS
+// atomicMin on (float bits of t << 32 | triangle): the closest hit is order independent; exact ties go to the lower
+// triangle index (the plain loop keeps the first one found — a measure-zero difference).  Pruning lags the plain loop by at
+// most one flush, so a few more nodes are visited per ray, at 2-3x the lane utilisation.
+#ifndef PT_CLOSEST_FLUSH_MIN
+#define PT_CLOSEST_FLUSH_MIN 64u      // measured: partial flushes (16/32/48) for earlier pruning cost more than they save
+#endif
+struct ClosestLds { uint32_t* ring; unsigned long long* best; uint32_t* pair; };   // ring[ANY_RING], best[64], pair[64]
+
+template <bool STATS>
+PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint32_t* stack, uint32_t lane, const ClosestLds& L, Hit& hit,
+                               StatCounters& st) {
+    if (!want) { rd = mk3(0.0f, 0.0f, 1.0f); ro = mk3(0.0f, 0.0f, 0.0f); }
+    RaySetup rs = setup_ray(rd);
+    const uint32_t kpack = (uint32_t)rs.kx | ((uint32_t)rs.ky << 2) | ((uint32_t)rs.kz << 4);
+    L.best[lane] = (0x7f7fffffull << 32) | 0xffffffffull;                 // (FLT_MAX, no triangle)
+    __syncthreads();
+    f3 w_ro = ro, w_inv = rs.inv; float w_tbest = 3.402823466e+38f; uint32_t owner = lane;
+    int sp = 0, sb = 0;
+    int32_t cur = sc.root;
+    uint32_t leaf_off = 0;
+    bool done = !want;
+    uint32_t head = 0, tail = 0;
+    if (STATS && want) st.closest_rays++;
+
+    auto flush = [&](uint32_t n) {
+        const bool valid = lane < n;
+        const uint32_t e = valid ? L.ring[(head + lane) & (ANY_RING - 1u)] : (lane << 26);
+        const uint32_t own = e >> 26, tri = e & 0x03ffffffu;
+        f3 o2 = mk3(__shfl(ro.x, own), __shfl(ro.y, own), __shfl(ro.z, own));
+        f3 d2 = mk3(__shfl(rd.x, own), __shfl(rd.y, own), __shfl(rd.z, own));
+        uint32_t kp = __shfl(kpack, own);
+        float sx = __shfl(rs.sx, own), sy = __shfl(rs.sy, own), sz = __shfl(rs.sz, own);
+        if (valid) {
+            const float t_lim = __uint_as_float((uint32_t)(L.best[own] >> 32));
+            TriVerts tv = load_tri(sc.tris, tri);
+            float t, b0, b1, b2;
+            if (STATS) { st.tris_closest++; if (wave_leader()) st.w[1]++; }
+            if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, t_lim, tv, t, b0, b1, b2))
+                atomicMin(&L.best[own], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)tri);
+        }
+        head += n;
+        __syncthreads();
+        w_tbest = fminf(w_tbest, __uint_as_float((uint32_t)(L.best[owner] >> 32)));
+    };
+
+    for (;;) {
+        if (!done && cur >= 0) {
+            const float4* q = (const float4*)(sc.nodes + cur);
+            float4 nx = q[0], ny = q[1], nz = q[2];
+            int2 ch = *(const int2*)(q + 3);
+            if (STATS) { st.nodes_closest++; if (wave_leader()) st.w[0]++; }
+            float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
+            float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
+            float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;
+            float l1y = (ny.y - w_ro.y) * w_inv.y, h1y = (ny.w - w_ro.y) * w_inv.y;
+            float l0z = (nz.x - w_ro.z) * w_inv.z, h0z = (nz.z - w_ro.z) * w_inv.z;
+            float l1z = (nz.y - w_ro.z) * w_inv.z, h1z = (nz.w - w_ro.z) * w_inv.z;
+            float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+            float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), w_tbest));
+            float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+            float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), w_tbest));
+            bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+            if (hit0 && hit1) {
+                bool first0 = n0 <= n1;
+                stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp;
+                cur = first0 ? ch.x : ch.y;
+            } else if (hit0) cur = ch.x;
+            else if (hit1) cur = ch.y;
+            else if (sp == sb) done = true;
+            else { --sp; cur = (int32_t)stack[sp * 64]; }
+        }
+        const bool at_leaf = !done && cur < 0;
+        const unsigned long long m1 = __ballot(at_leaf);
+        if (m1 != 0ull) {
+            uint32_t first = 0, rem = 0;
+            if (at_leaf) { first = leaf_first(cur) + leaf_off; rem = leaf_count(cur) - leaf_off; }
+            const uint32_t a = rem < 2u ? rem : 2u;
+            const unsigned long long m2 = __ballot(a == 2u);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t pos = tail + (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
+            if (a >= 1u) L.ring[pos & (ANY_RING - 1u)] = first | (owner << 26);
+            if (a == 2u) L.ring[(pos + 1u) & (ANY_RING - 1u)] = (first + 1u) | (owner << 26);
+            tail += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+            if (at_leaf) {
+                if (rem > 2u) leaf_off += 2u;
+                else { leaf_off = 0u; if (sp == sb) done = true; else { --sp; cur = (int32_t)stack[sp * 64]; } }
+            }
+            __syncthreads();
+            while (tail - head >= 64u) flush(64u);
+            if (tail - head >= PT_CLOSEST_FLUSH_MIN) flush(tail - head);      // early feedback of t_best
+        }
+        const unsigned long long m_act = __ballot(!done);
+        if (m_act == 0ull) break;
+#if PT_ANY_STEAL
+        if (__popcll(m_act) <= PT_STEAL_MAX_ACTIVE) {
+            const unsigned long long m_donor = __ballot(!done && sp > sb);
+            if (m_donor != 0ull) {
+                const unsigned long long m_idle = ~m_act;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t n_pairs = min((uint32_t)__popcll(m_donor), (uint32_t)__popcll(m_idle));
+                const bool donor = !done && sp > sb;
+                const uint32_t rank = (uint32_t)__popcll((donor ? m_donor : m_idle) & below);
+                if (donor && rank < n_pairs) L.pair[rank] = lane;
+                __syncthreads();
+                const bool taker = done && rank < n_pairs;
+                const uint32_t from = taker ? L.pair[rank] : lane;
+                const int d_sb = __shfl(sb, from);
+                const float rx = __shfl(w_ro.x, from), ry = __shfl(w_ro.y, from), rz = __shfl(w_ro.z, from);
+                const float ix = __shfl(w_inv.x, from), iy = __shfl(w_inv.y, from), iz = __shfl(w_inv.z, from);
+                const float tb = __shfl(w_tbest, from);
+                const uint32_t ow = __shfl(owner, from);
+                if (taker) {
+                    cur = (int32_t)(stack - lane)[d_sb * 64 + from];
+                    w_ro = mk3(rx, ry, rz); w_inv = mk3(ix, iy, iz); w_tbest = tb; owner = ow;
+                    sp = sb = 0; leaf_off = 0u; done = false;
+                }
+                if (donor && rank < n_pairs) ++sb;
+                __syncthreads();
+            }
+        }
+#endif
+    }
+    if (tail != head) flush(tail - head);
+    const unsigned long long key = L.best[lane];
+    const uint32_t tri = (uint32_t)key;
+    const bool found = want && tri != 0xffffffffu;
+    if (found) {                                                             // the winner's barycentrics: same function, same inputs
+        TriVerts tv = load_tri(sc.tris, tri);
+        float t, b0, b1, b2;
+        intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
+        hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = tri;
+        if (STATS) st.closest_hits++;
+    }
+    return found;
 }
 
 }  // namespace pt

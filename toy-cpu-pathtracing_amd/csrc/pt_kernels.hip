@@ -71,6 +71,9 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 #ifndef PT_ANY_DEFERRED
 #define PT_ANY_DEFERRED 1
 #endif
+#ifndef PT_CLOSEST_COOP
+#define PT_CLOSEST_COOP 1      // needs PT_ANY_DEFERRED (shares its LDS ring)
+#endif
 template <bool STATS, bool PROBE, uint32_t FEAT>
 __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, unsigned* __restrict__ work_counter,
@@ -83,7 +86,12 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
 #if PT_ANY_DEFERRED
     __shared__ uint32_t s_ring[ANY_RING];
     __shared__ uint32_t s_occl[2];
-    const AnyLds any_lds{s_ring, s_occl};
+    __shared__ uint32_t s_pair[64];
+    const AnyLds any_lds{s_ring, s_occl, s_pair};
+#if PT_CLOSEST_COOP
+    __shared__ unsigned long long s_best[64];
+    const ClosestLds closest_lds{s_ring, s_best, s_pair};
+#endif
 #endif
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < (uint32_t)HASH_TABLE_DIMS; i += 64) s_hash[i] = dim_hash_tab[i];
@@ -124,7 +132,11 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
             if (STATS) ts1 = __builtin_amdgcn_s_memtime();
             Hit hit{};
             bool got = false;
+#if PT_CLOSEST_COOP
+            got = trace_closest_coop<STATS>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st);
+#else
             if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st);
+#endif
             if (STATS) ts2 = __builtin_amdgcn_s_memtime();
             bool end_path = false;
             ShadowReq sh{};
