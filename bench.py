@@ -210,7 +210,7 @@ def main():
 
 
 def scene_info(prod, scene):
-    return "flat single-level BVH2 (sweep SAH), 64 B nodes with both child boxes, <=2 tris/leaf"
+    return "flat single-level BVH2 (sweep SAH), 64 B nodes with both child boxes, <=2 tris/leaf; " + prod.scene_info(scene)
 
 
 if __name__ == "__main__":

@@ -160,6 +160,9 @@ int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const
  * scene.rs:64-76 */
 int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam);
 
+/* Diagnostic: "nodes=.. tris=.. depth=.. features=.." of the built scene (no reference counterpart). */
+int mi355pt_scene_info(const mi355pt_scene* s, char* buf, size_t buf_size);
+
 /* ---------------- rendering ---------------- */
 /* RendererImage::render::<S>() + Sensor::to_rgb: fills out_rgb (host, W*H*3, row-major, y down) with
  * tone-mapped sRGB-encoded values in [0,1] exactly like RendererImage.pixels.  renderer.rs:101-134, sensor.rs:81-88 */

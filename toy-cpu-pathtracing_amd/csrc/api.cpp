@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -363,6 +364,12 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     return MI355PT_OK;   // stats == NULL: fully asynchronous on `stream`
 }
 
+int mi355pt_scene_info(const mi355pt_scene* s, char* buf, size_t n) {
+    if (!s || !buf || n == 0) return fail(MI355PT_E_INVALID, "null argument");
+    if (!s->impl.built) return fail(MI355PT_E_INVALID, "scene not built");
+    std::snprintf(buf, n, "%s features=%u", s->impl.info.c_str(), s->impl.features);
+    return MI355PT_OK;
+}
 int mi355pt_film_resolve_device(const float* d_accum, uint32_t n_pixels, uint32_t spp, float* d_out, void* hip_stream) {
     if (!d_accum || !d_out || spp == 0) return fail(MI355PT_E_INVALID, "bad resolve arguments");
     HIP_TRY(launch_resolve(d_accum, n_pixels * 3, spp, d_out, (hipStream_t)hip_stream));

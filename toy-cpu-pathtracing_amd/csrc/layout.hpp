@@ -23,9 +23,9 @@
 
 namespace pt {
 
-constexpr int STACK_DEPTH = 26;        // per-lane traversal stack entries kept in LDS (6.5 KB per wave)
+constexpr int STACK_DEPTH = 24;        // per-lane traversal stack entries kept in LDS (6 KB per wave)
 constexpr int MAX_LEAF_TRIS = 4;
-constexpr int MAX_BUILD_DEPTH = 24;    // builder guarantees depth <= this (< STACK_DEPTH)
+constexpr int MAX_BUILD_DEPTH = 22;    // builder guarantees depth <= this (< STACK_DEPTH)
 constexpr int HASH_TABLE_DIMS = 136;   // precomputed murmur(dimension, seed) entries: 3 + 16 bounces x 8 draws
                                        // LDS per wave: 7168 (stack) + 1088 (hash) + 544 (Sobol prefixes) = 8.8 KB -> 16 waves/CU fit in 160 KB
 

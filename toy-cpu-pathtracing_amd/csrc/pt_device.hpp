@@ -134,6 +134,7 @@ struct SamplerCtx {
     const uint32_t* hi_lds;       // per-dimension permuted high digits of this wave's 8x8 tile, >> hi_shift (nullptr: none)
     uint32_t hi_first;            // first digit index covered by hi_lds
     uint32_t hi_shift;            // bit position of that digit
+    const uint32_t* p6_lds;       // per dimension: the permutation indices of digit hi_first-2 for the four values of digit hi_first-1
 };
 // The pixels of an aligned 8x8 tile share every Morton digit above the lowest three, and a digit's permutation
 // only depends on the digits above it and on the dimension (:134-145): for those digits the permuted prefix of the
@@ -158,12 +159,26 @@ PT_DEV uint64_t sobol_tile_hi_digits(uint32_t tile_morton_shifted, uint32_t dime
 #endif
     return out;
 }
+// permutation index (0..23) of the digit whose higher digits are `higher` (z_sobol_sampler.rs:134-145)
+PT_DEV uint32_t sobol_perm_index(uint64_t higher, uint32_t dimension) {
+    uint64_t mx = mix_bits(higher ^ (0x55555555ull * (uint64_t)dimension)) >> 24;
+    return (((uint32_t)(mx >> 32) * 16u) + ((uint32_t)mx % 24u)) % 24u;
+}
 PT_DEV uint64_t sampler_index(const Sampler& s, const SamplerCtx& c) {
 #ifdef PT_SOBOL_ABLATE   // timing experiment only: skips the digit permutation (wrong sequence)
     return (uint64_t)s.morton;
 #endif
-    if (c.hi_lds != nullptr && s.dimension < (uint32_t)SOBOL_HI_DIMS)
-        return sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits, (uint64_t)c.hi_lds[s.dimension] << c.hi_shift, c.hi_first);
+    if (c.hi_lds != nullptr && s.dimension < (uint32_t)SOBOL_HI_DIMS) {
+        // tile-uniform prefix, plus the two digits below it through tile-uniform permutation indices: the permutation of digit
+        // hi_first-1 depends on the prefix only, the one of digit hi_first-2 on the prefix and the 4 values of digit hi_first-1
+        const uint32_t e = c.hi_lds[s.dimension], e6 = c.p6_lds[s.dimension];
+        const uint32_t sh7 = c.hi_shift - 2u, sh6 = c.hi_shift - 4u;
+        const uint32_t d7 = (s.morton >> sh7) & 3u, d6 = (s.morton >> sh6) & 3u;
+        const uint32_t q7 = (perm_packed(e >> 27) >> (2u * d7)) & 3u;
+        const uint32_t q6 = (perm_packed((e6 >> (5u * d7)) & 31u) >> (2u * d6)) & 3u;
+        uint64_t hi = ((uint64_t)(e & 0x07ffffffu) << c.hi_shift) | ((uint64_t)q7 << sh7) | ((uint64_t)q6 << sh6);
+        return sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits, hi, c.hi_first - 2u);
+    }
     return sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits);
 }
 

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
     __shared__ uint64_t s_hash[HASH_TABLE_DIMS];
     __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
+    __shared__ uint32_t s_p6[SOBOL_HI_DIMS];
     __shared__ unsigned s_work;
 #if PT_ANY_DEFERRED
     __shared__ uint32_t s_ring[ANY_RING];
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
     for (uint32_t i = lane; i < (uint32_t)HASH_TABLE_DIMS; i += 64) s_hash[i] = dim_hash_tab[i];
     __syncthreads();
     uint32_t* stack = s_stack + lane;
-    SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash, nullptr, 0u, 0u};
+    SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, s_hash, nullptr, 0u, 0u, nullptr};
     StatCounters st{};
 
     for (;;) {
@@ -112,9 +113,16 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
             uint32_t tile_px = __shfl(job.px, 0), tile_py = __shfl(job.py, 0);
             sctx.hi_first = sobol_hi_first(prm.log2_spp);
             sctx.hi_shift = 2u * sctx.hi_first - (prm.log2_spp & 1u);
-            for (uint32_t dmn = lane; dmn < (uint32_t)SOBOL_HI_DIMS; dmn += 64)
-                s_hi[dmn] = (uint32_t)(sobol_tile_hi_digits(encode_morton2_u32(tile_px, tile_py) << prm.log2_spp, dmn, prm.log2_spp, prm.n_base4_digits) >> sctx.hi_shift);
-            sctx.hi_lds = s_hi;
+            const uint32_t tile_m = encode_morton2_u32(tile_px, tile_py) << prm.log2_spp;
+            for (uint32_t dmn = lane; dmn < (uint32_t)SOBOL_HI_DIMS; dmn += 64) {
+                uint32_t e = (uint32_t)(sobol_tile_hi_digits(tile_m, dmn, prm.log2_spp, prm.n_base4_digits) >> sctx.hi_shift);   // <= 26 bits: the Morton index is a u32 and hi_shift >= 6
+                const uint64_t prefix = (uint64_t)tile_m >> sctx.hi_shift;                 // the digits above digit hi_first-1
+                e |= sobol_perm_index(prefix, dmn) << 27;
+                uint32_t e6 = 0;
+                for (uint32_t v7 = 0; v7 < 4u; ++v7) e6 |= sobol_perm_index((prefix << 2) | v7, dmn) << (5u * v7);
+                s_hi[dmn] = e; s_p6[dmn] = e6;
+            }
+            sctx.hi_lds = s_hi; sctx.p6_lds = s_p6;
             __syncthreads();
         }
         uint32_t s_cur = job.s_cur;

@@ -100,7 +100,7 @@ def _ptr(a, ty):
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
     "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_build", "render", "render_accum_device", "film_resolve_device",
-    "quantize_u8", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "last_error", "version",
+    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "last_error", "version",
 ]
 
 
@@ -285,6 +285,12 @@ class Product(Backend):
 
     def version(self):
         return self.lib.mi355pt_version().decode()
+
+    def scene_info(self, scene):
+        buf = C.create_string_buffer(256)
+        self.lib.mi355pt_scene_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        self.check(self.lib.mi355pt_scene_info(scene.h, buf, 256), "scene_info")
+        return buf.value.decode()
 
     def render(self, scene, cam, params, want_stats=False):
         """RendererImage::render -> (H, W, 3) float32 tone-mapped sRGB in [0,1] (renderer.rs:120-134)."""
