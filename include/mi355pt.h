@@ -111,7 +111,9 @@ typedef struct mi355pt_params {
     /* multi-GPU sharding of the pixel loop (renderer.rs:121): this call renders only the 8x8
      * pixel tiles t with t % shard_count == shard_index; other pixels are left untouched. */
     uint32_t shard_index, shard_count; /* 0,1 (or 0,0) = whole frame */
-    uint32_t collect_stats;            /* 1 = run the instrumented kernel variant and fill mi355pt_stats */
+    uint32_t collect_stats;            /* run the instrumented kernel variant and fill mi355pt_stats: 1 = with the reference's
+                                        * traversal order (the canonical per-sample node/triangle counts of SURVEY.md 8d),
+                                        * 2 = with the production traversal (cooperative, slightly more nodes; lane-use diagnostics) */
 } mi355pt_params;
 
 typedef struct mi355pt_stats {

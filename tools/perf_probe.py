@@ -42,7 +42,7 @@ for i in range(a.reps + 1):
     ms.append(st.kernel_ms)
 best = min(ms[1:])
 rate = a.width * a.height * a.slice / best / 1e3
-prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=1, max_depth=a.max_depth)
+prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=2, max_depth=a.max_depth)
 st = pkg.ffi.Stats()
 prod.render_accum_device(sc, cam, prm2, 0, a.slice, d_acc.value, None, stats=st)
 d = st.as_dict()

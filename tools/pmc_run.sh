@@ -8,8 +8,10 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
+MAXL=${PMC_LINES:-99}
 while read -r line; do
   [ -z "$line" ] && continue
+  [ $i -ge $MAXL ] && break
   timeout -k 10 200 rocprofv3 --pmc $line --output-format csv -d $OUT/p$i -- python3 $R/tools/perf_probe.py --reps 2 "$@" > $OUT/p$i.log 2>&1
   i=$((i+1))
 done <<'LIST'

@@ -337,6 +337,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     DevStats* d_stats = lc->d_stats + slot;
     HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned), stream));
     bool want_stats = stats && p->collect_stats;
+    dp.stats_mode = p->collect_stats;
     if (want_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (stats) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }

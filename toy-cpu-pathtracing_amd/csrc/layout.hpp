@@ -170,6 +170,7 @@ struct DevParams {
     uint32_t tiles_x, tiles_y;
     uint32_t n_work;                        // tiles * sample chunks handled by this launch
     uint32_t chunks, chunk_size;            // sample-range split per tile (1 = none)
+    uint32_t stats_mode;                    // instrumented variant only: 1 = reference traversal order (canonical counts), 2 = production traversal
     float xyz_to_rgb[9];                    // row-major sRGB matrix (gamut.rs:50-63)
 };
 

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
             Hit hit{};
             bool got = false;
 #if PT_CLOSEST_COOP
-            got = trace_closest_coop<STATS>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st);
+            if (STATS && prm.stats_mode == 1u) { if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st); }
+            else got = trace_closest_coop<STATS>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st);
 #else
             if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st);
 #endif
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
 #if PT_ANY_DEFERRED
             if (__any(sh.on)) {
                 if (STATS && sh.on) st.w[6]++;
-                bool occluded = trace_any_deferred<STATS>(sc, sh.o, sh.d, sh.t, sh.on, stack, lane, any_lds, st);
+                bool occluded = false;
+                if (STATS && prm.stats_mode == 1u) { if (sh.on) occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st); }
+                else occluded = trace_any_deferred<STATS>(sc, sh.o, sh.d, sh.t, sh.on, stack, lane, any_lds, st);
                 if (sh.on && !occluded) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
