@@ -22,6 +22,7 @@ ap.add_argument("--strategy", default="mis")
 ap.add_argument("--sampler", default="sobol")
 ap.add_argument("--tag", default="")
 ap.add_argument("--max-depth", type=int, default=16)
+ap.add_argument("--shards", type=int, default=1, help="render only shard 0 of N (emulates one rank of an N-GPU job)")
 a = ap.parse_args()
 
 pkg = importlib.import_module("toy-cpu-pathtracing_amd")
@@ -34,15 +35,15 @@ n = a.width * a.height * 3 * 4
 d_acc = C.c_void_p()
 assert hip.hipMalloc(C.byref(d_acc), C.c_size_t(n)) == 0
 hip.hipMemset(d_acc, 0, C.c_size_t(n))
-prm = pkg.make_params(a.spp, a.strategy, a.sampler, max_depth=a.max_depth)
+prm = pkg.make_params(a.spp, a.strategy, a.sampler, max_depth=a.max_depth, shard_index=0, shard_count=a.shards)
 ms = []
 for i in range(a.reps + 1):
     st = pkg.ffi.Stats()
     prod.render_accum_device(sc, cam, prm, i * a.slice, (i + 1) * a.slice, d_acc.value, None, stats=st)
     ms.append(st.kernel_ms)
 best = min(ms[1:])
-rate = a.width * a.height * a.slice / best / 1e3
-prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=2, max_depth=a.max_depth)
+rate = a.width * a.height * a.slice / a.shards / best / 1e3
+prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=2, max_depth=a.max_depth, shard_index=0, shard_count=a.shards)
 st = pkg.ffi.Stats()
 prod.render_accum_device(sc, cam, prm2, 0, a.slice, d_acc.value, None, stats=st)
 d = st.as_dict()

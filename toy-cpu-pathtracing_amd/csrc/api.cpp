@@ -329,6 +329,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     uint32_t n_samples = s_end - s_begin;
     uint32_t chunks = 1;
     while (n_tiles * chunks < (uint32_t)waves * 4 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 8) chunks *= 2;
+    if (const char* e = getenv("MI355PT_CHUNKS")) { uint32_t c = (uint32_t)atoi(e); if (c >= 1 && c <= n_samples) chunks = c; }   // tuning experiment
     dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
     dp.n_work = n_tiles * chunks;
     LaunchCtx* lc; int slot;

@@ -17,6 +17,9 @@
 //  * shadow rays use deferred, dense triangle tests (trace_any_deferred, pt_device.hpp): lanes only walk nodes and
 //    queue (triangle, lane) pairs in an LDS ring, the wave tests 64 pairs at a time (any-hit is order independent).
 //    Measured on C2: any-hit triangle steps per wave iteration 24 at 3.7 % lane use -> 1.8 at 72 %, +4-5 % Msamples/s;
+//  * measured and dropped: two work items in flight per wave (a lane that finished its pixel starts the next tile's instead of
+//    idling; lanes busy at shading 89 % -> 96 %, but the extra per-lane state spills and the hash table had to leave LDS:
+//    -6 % at one GPU, +-0 on a 1/8 shard), a per-lane cache of the in-tile Sobol digits (not wave-uniform: -3 %);
 //  * BVH traversal keeps the per-lane stack in LDS (stack[level][lane], conflict-free) and the
 //    MurmurHash(dimension, seed) table of the Sobol sampler in LDS.
 #include <hip/hip_runtime.h>
