@@ -75,6 +75,10 @@ typedef struct mi355pt_material_desc {
     float metallic, ior, clearcoat_ior, clearcoat_roughness, clearcoat_thickness;
     mi355pt_spectrum clearcoat_tint;
     mi355pt_spectrum k;     /* metal only: extinction coefficient */
+    /* FloatParameter::texture(FloatTexture::load(path, false)) for metallic / roughness (SimplePbr, clearcoat) and the metal's
+     * roughness: texture ids from add_tex_rgb8 (a grey image replicated to RGB; the red channel is read with the same bilinear
+     * rule, texture/sampler.rs:81-107), MI355PT_NONE = the constant above.  material/parameter.rs:58-83 */
+    uint32_t metallic_tex, roughness_tex;
 } mi355pt_material_desc;
 
 /* ---- delta lights: CreatePrimitiveDesc::{PointLightPrimitive, SpotLightPrimitive, DirectionalLightPrimitive}

@@ -453,6 +453,7 @@ struct MaterialEval {
 // ---------------- SimpleClearcoatPbrMaterial (impls/simple_pbr_clearcoat_material.rs) ----------------
 struct Clearcoat {
     const Material& m; SS base_color, tint; uint64_t key;
+    float metallic, roughness;     // FloatParameter values at the shading point
     static float r2a(float r) { return r * r; }                                            // :76-78
     static float diel_r0(float ior) { float r = (ior - 1.0f) / (ior + 1.0f); return r * r; }   // :81-84
     static SS attenuation(SS tint, float thickness, float cos_theta) {                     // :88-107
@@ -463,8 +464,8 @@ struct Clearcoat {
         return ss_exp((-1.0f * sigma) * l);
     }
     GenSchlickBsdf coat() const { return GenSchlickBsdf{SS::constant(diel_r0(m.cc_ior)), SS::one(), 5.0f, SS::one(), r2a(m.cc_roughness), r2a(m.cc_roughness)}; }
-    GenSchlickBsdf metal(SS r0) const { float a = r2a(m.roughness); return GenSchlickBsdf{r0, SS::one(), 5.0f, SS::one(), a, a}; }
-    GenSchlickBsdf diel() const { float a = r2a(m.roughness); return GenSchlickBsdf{SS::constant(diel_r0(m.cc_base_ior)), SS::one(), 5.0f, SS::one(), a, a}; }
+    GenSchlickBsdf metal(SS r0) const { float a = r2a(roughness); return GenSchlickBsdf{r0, SS::one(), 5.0f, SS::one(), a, a}; }
+    GenSchlickBsdf diel() const { float a = r2a(roughness); return GenSchlickBsdf{SS::constant(diel_r0(m.cc_base_ior)), SS::one(), 5.0f, SS::one(), a, a}; }
 
     // sample_base_material (:336-383) in the normal-map frame; returns BsdfSample with wi in that frame
     bool sample_metallic(V3 wo, V2 uv, BsdfSample* out) const { return metal(base_color).sample_R(wo, uv, out); }     // :455-493
@@ -481,10 +482,10 @@ struct Clearcoat {
         b.f = b.f * (1.0f - fr); b.pdf = b.pdf * (1.0f - fr); *out = b; return true;
     }
     bool sample_base(V3 wo, float uc, V2 uv, BsdfSample* out) const {
-        if (m.cc_metallic >= 1.0f) return sample_metallic(wo, uv, out);
-        if (m.cc_metallic <= 0.0f) return sample_dielectric(wo, uc, uv, out);
-        if (uc <= m.cc_metallic) return sample_metallic(wo, uv, out);                                                  // sample_mixed :552-578
-        return sample_dielectric(wo, (uc - m.cc_metallic) / (1.0f - m.cc_metallic), uv, out);
+        if (metallic >= 1.0f) return sample_metallic(wo, uv, out);
+        if (metallic <= 0.0f) return sample_dielectric(wo, uc, uv, out);
+        if (uc <= metallic) return sample_metallic(wo, uv, out);                                                  // sample_mixed :552-578
+        return sample_dielectric(wo, (uc - metallic) / (1.0f - metallic), uv, out);
     }
     SS eval_dielectric(V3 wo, V3 wi) const {                                                                            // :603-633
         GenSchlickBsdf g = diel();
@@ -493,9 +494,9 @@ struct Clearcoat {
         return direct + (1.0f - fr) * lambert_evaluate(base_color, wo, wi);
     }
     SS eval_base(V3 wo, V3 wi) const {                                                                                  // :384-417
-        if (m.cc_metallic >= 1.0f) return metal(base_color).evaluate_R(wo, wi);
-        if (m.cc_metallic <= 0.0f) return eval_dielectric(wo, wi);
-        return metal(base_color).evaluate_R(wo, wi) * m.cc_metallic + eval_dielectric(wo, wi) * (1.0f - m.cc_metallic);
+        if (metallic >= 1.0f) return metal(base_color).evaluate_R(wo, wi);
+        if (metallic <= 0.0f) return eval_dielectric(wo, wi);
+        return metal(base_color).evaluate_R(wo, wi) * metallic + eval_dielectric(wo, wi) * (1.0f - metallic);
     }
     float pdf_dielectric(V3 wo, V3 wi) const {                                                                          // :646-675
         GenSchlickBsdf g = diel();
@@ -504,9 +505,9 @@ struct Clearcoat {
         return fr * direct + (1.0f - fr) * lambert_pdf(wo, wi);
     }
     float pdf_base(V3 wo, V3 wi) const {                                                                                // :418-454
-        if (m.cc_metallic >= 1.0f) return metal(SS::one()).pdf_R(wo, wi);
-        if (m.cc_metallic <= 0.0f) return pdf_dielectric(wo, wi);
-        return metal(SS::one()).pdf_R(wo, wi) * m.cc_metallic + pdf_dielectric(wo, wi) * (1.0f - m.cc_metallic);
+        if (metallic >= 1.0f) return metal(SS::one()).pdf_R(wo, wi);
+        if (metallic <= 0.0f) return pdf_dielectric(wo, wi);
+        return metal(SS::one()).pdf_R(wo, wi) * metallic + pdf_dielectric(wo, wi) * (1.0f - metallic);
     }
     float coat_weight(V3 wo) const { return coat().directional_albedo(wo, key).average(); }                             // :190-192
 };
@@ -514,7 +515,8 @@ struct Clearcoat {
 inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, Wavelengths& wl, V3 wo, const ShadingPoint& sp) const {
     MaterialSample ms;
     if (m.type == MAT_CLEARCOAT) {                                           // simple_pbr_clearcoat_material.rs:137-260
-        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key};
+        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
+                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv)};
         M4 tf = normal_map_transform(m, sp.uv);
         M4 tf_inv = inverse(tf);
         V3 wo_nm = transform_vector3(tf, wo);
@@ -542,7 +544,8 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
         M4 tf = normal_map_transform(m, sp.uv);
         M4 tf_inv = inverse(tf);
         V3 wo_nm = transform_vector3(tf, wo);
-        float alpha = m.roughness * m.roughness;
+        float rough = scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv);
+        float alpha = rough * rough;
         ConductorBsdf bsdf{eta, k, alpha, alpha};
         BsdfSample bs;
         if (!bsdf.sample(wo_nm, uv, &bs)) return ms;
@@ -584,7 +587,8 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
 
 inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const {
     if (m.type == MAT_CLEARCOAT) {                                           // :261-341
-        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key};
+        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
+                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv)};
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
         if (m.cc_thickness <= 0.0f) return cc.eval_base(wo_nm, wi_nm);
@@ -599,7 +603,8 @@ inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
         if (signum(dot(sp.normal, wi)) != signum(dot(sp.normal, wo))) return SS::zero();
-        float alpha = m.roughness * m.roughness;
+        float rough = scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv);
+        float alpha = rough * rough;
         return ConductorBsdf{eta, k, alpha, alpha}.evaluate(wo_nm, wi_nm);
     }
     if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:99-131
@@ -624,7 +629,8 @@ inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo
 
 inline float MaterialEval::pdf(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const {
     if (m.type == MAT_CLEARCOAT) {                                           // :342-433
-        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key};
+        Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
+                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv)};
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
         if (m.cc_thickness <= 0.0f) return cc.pdf_base(wo_nm, wi_nm);
@@ -635,7 +641,8 @@ inline float MaterialEval::pdf(const Material& m, const Wavelengths& wl, V3 wo, 
         M4 tf = normal_map_transform(m, sp.uv);
         if (signum(dot(sp.normal, wi)) != signum(dot(sp.normal, wo))) return 0.0f;
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
-        float alpha = m.roughness * m.roughness;
+        float rough = scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv);
+        float alpha = rough * rough;
         return ConductorBsdf{m.eta.sample(wl), m.k.sample(wl), alpha, alpha}.pdf(wo_nm, wi_nm);
     }
     if (m.type == MAT_LAMBERT) {                                             // lambert_material.rs:133-159

@@ -28,6 +28,7 @@ struct Material {
     float intensity = 1.0f;        // Emissive FloatParameter::Constant
     Spectrum eta;                  // Glass: LUT spectrum; Plastic: constant; Metal: real part of the index
     Spectrum k;                    // Metal: extinction coefficient (presets::au_k() ...)
+    int metallic_tex = -1, roughness_tex = -1;   // FloatParameter::Texture (grey image in the red channel), -1 = constant
     bool thin = false;
     float roughness = 0.0f;
     // clearcoat (simple_pbr_clearcoat_material.rs): filled by the API when type == MAT_CLEARCOAT
@@ -361,6 +362,14 @@ struct Scene {
         Spectrum s; s.kind = SPEC_SIGMOID;
         table.get_srgb_encoded(rgb, s.c);
         return s.sample(w);
+    }
+
+    // FloatParameter::sample (parameter.rs:65-72) -> FloatTexture::sample, gamma_corrected = false (float_texture.rs:33-52)
+    float sample_float_param(float constant, int tex, V2 uv) const {
+        if (tex < 0) return constant;
+        float rgb[3];
+        bilinear_sample_rgb(textures[tex], uv, rgb);
+        return rgb[0];
     }
 
     // ---- lights ----

@@ -97,6 +97,9 @@ int ptoracle_scene_add_material(ptoracle_scene* s, const mi355pt_material_desc* 
     m.intensity = d->intensity;
     if (d->type == MI355PT_MAT_GLASS || d->type == MI355PT_MAT_PLASTIC) { if (!lower_spectrum(s, d->eta, &m.eta)) return -1; }
     m.thin = d->thin != 0; m.roughness = d->roughness;
+    m.metallic_tex = d->metallic_tex == MI355PT_NONE ? -1 : (int)d->metallic_tex;
+    m.roughness_tex = d->roughness_tex == MI355PT_NONE ? -1 : (int)d->roughness_tex;
+    if (m.metallic_tex >= (int)s->scene.textures.size() || m.roughness_tex >= (int)s->scene.textures.size()) return -1;
     if (d->type == MI355PT_MAT_METAL) { if (!lower_spectrum(s, d->eta, &m.eta) || !lower_spectrum(s, d->k, &m.k)) return -1; }
     if (d->type == MI355PT_MAT_SIMPLE_PBR) {     // SimplePbrMaterial == the clearcoat material's base layer (thickness 0 takes that path)
         m.type = MAT_CLEARCOAT; m.cc_metallic = d->metallic; m.cc_base_ior = d->ior; m.cc_thickness = 0.0f;

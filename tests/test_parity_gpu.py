@@ -154,13 +154,14 @@ def test_gpu_pt_nee_mis_consistency_metal(product, pkg):
 
 @pytest.mark.parametrize("scene_id,strategy", [(8, "mis"), (10, "mis"), (0, "nee"), (17, "nee"), (17, "mis"), (11, "mis"), (11, "nee"),
                                                (6, "mis"), (7, "mis"), (7, "nee"), (20, "mis"), (20, "pt"),
-                                               (1, "nee"), (2, "mis"), (21, "mis"), (21, "nee"), (19, "mis"), (19, "pt"), (19, "nee")])
+                                               (1, "nee"), (2, "mis"), (21, "mis"), (21, "nee"), (19, "mis"), (19, "pt"), (19, "nee"), (22, "mis"), (22, "nee")])
 def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     """Glass (scene 8: dispersive, wavelength termination), thin plastic (scene 10), plain Lambert (scene 0), rough clearcoat
     over rough metal (scene 17), rough SF11 glass (scene 11: microfacet reflection/transmission + light connection), smooth
     gold (scene 6), four instanced rough-gold heroes (scene 7: ConductorBsdf + complex Fresnel), SimplePbrMaterial with
     mixed metallic (scene 20, not a reference scene), point lights only (scenes 1, 2), spot + directional + area light
-    together (scene 21, not a reference scene), environment light over SimplePbr / clearcoat / plastic heroes (scene 19)."""
+    together (scene 21, not a reference scene), environment light over SimplePbr / clearcoat / plastic heroes (scene 19), SimplePbr with FloatTexture metallic / roughness maps,
+    textured base colour and a normal map (scene 22, scene 15's material on a stand-in mesh)."""
     pair = {}
     for name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()

@@ -90,8 +90,10 @@ struct alignas(16) DevMaterial {
     DevSpectrum color;
     DevSpectrum eta;       // glass: LUT, plastic: constant
     DevSpectrum cc_tint;   // clearcoat tint; metal: extinction coefficient k
+    uint32_t metallic_tex, roughness_tex;   // FloatParameter::Texture ids (red channel), ~0 = use the constants above
+    uint32_t pad1[2];
 };
-static_assert(sizeof(DevMaterial) == 144, "material record");
+static_assert(sizeof(DevMaterial) == 160, "material record");
 
 struct alignas(16) DevLightTri {
     float p0[3]; float p1x;

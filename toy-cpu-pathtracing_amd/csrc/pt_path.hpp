@@ -384,7 +384,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
             bool d_thin = false, d_plastic = false;
             float albedo[4] = {0, 0, 0, 0};   // Lambert albedo / clearcoat base colour
             float cc_tint[4] = {1, 1, 1, 1};
-            float cc_fc = 0.0f, cc_alpha_c = 0.0f, cc_alpha_b = 0.0f, cc_r0c = 0.0f, cc_r0d = 0.0f;
+            float cc_fc = 0.0f, cc_alpha_c = 0.0f, cc_alpha_b = 0.0f, cc_r0c = 0.0f, cc_r0d = 0.0f, cc_metallic = 0.0f;
 
             if (mtype == MT_LAMBERT) {
                 // LambertMaterial::sample (lambert_material.rs:42-97) + NormalizedLambertBsdf (lambert.rs:38-75)
@@ -532,9 +532,16 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
                 DevSpectrum ts = load_spectrum(&mat->cc_tint);
                 eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ts, wl, sf.uv, cc_tint, st);
-                const float metallic = mat->metallic, thick = mat->cc_thickness;
+                float metallic = mat->metallic; const float thick = mat->cc_thickness;
+                float rough_b = mat->roughness;
+                if (FEAT & FEAT_TEX) {                                          // FloatParameter::Texture (parameter.rs:65-72)
+                    float t3[3];
+                    if (mat->metallic_tex != 0xffffffffu) { bilinear_rgb(sc, mat->metallic_tex, sf.uv, t3); metallic = t3[0]; }
+                    if (mat->roughness_tex != 0xffffffffu) { bilinear_rgb(sc, mat->roughness_tex, sf.uv, t3); rough_b = t3[0]; }
+                }
+                cc_metallic = metallic;
                 cc_alpha_c = mat->cc_roughness * mat->cc_roughness;                 // roughness_to_alpha :76-78
-                cc_alpha_b = mat->roughness * mat->roughness;
+                cc_alpha_b = rough_b * rough_b;
                 { float r = (mat->cc_ior - 1.0f) / (mat->cc_ior + 1.0f); cc_r0c = r * r; }   // compute_dielectric_r0 :81-84
                 { float r = (mat->ior - 1.0f) / (mat->ior + 1.0f); cc_r0d = r * r; }
                 // coat weight: 64-sample Monte Carlo of the coat's directional albedo, ONE stream per path vertex.
@@ -610,7 +617,10 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 DevSpectrum es = load_spectrum(&mat->eta), ks = load_spectrum(&mat->cc_tint);
                 eval_spectrum<STATS, false>(sc, es, wl, sf.uv, albedo, st);
                 eval_spectrum<STATS, false>(sc, ks, wl, sf.uv, cc_tint, st);
-                const float alpha = mat->roughness * mat->roughness;            // roughness_to_alpha :69-71
+                float rough_m = mat->roughness;
+                if ((FEAT & FEAT_TEX) && mat->roughness_tex != 0xffffffffu) { float t3[3]; bilinear_rgb(sc, mat->roughness_tex, sf.uv, t3); rough_m = t3[0]; }
+                const float alpha = rough_m * rough_m;                          // roughness_to_alpha :69-71
+                cc_alpha_b = alpha;                                             // kept for the light connection
                 if (wo_nm.z != 0.0f) {
                     f3 wi = mk3(0, 0, 1); bool okm = false;
                     if (alpha < 1e-3f) {                                        // sample_specular :276-298
@@ -796,7 +806,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                             for (int i = 0; i < 4; ++i) fl[i] = fl[i] * col[i];
                         }
                     } else if ((FEAT & FEAT_METAL) && nee_kind == 4u) {          // MetalMaterial::{evaluate,pdf} (metal_material.rs:150-229)
-                        const float alpha = mat->roughness * mat->roughness;
+                        const float alpha = cc_alpha_b;
                         if (sgn1(gwi) == sgn1(geo_wo) && !(alpha < 1e-3f) && fabsf(wo_nm.z) != 0.0f && fabsf(wi_nm.z) != 0.0f && wo_nm.z * wi_nm.z > 0.0f) {
                             f3 h = wo_nm + wi_nm;
                             if (dot(h, h) != 0.0f) {
@@ -819,7 +829,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         float dgc, p5c, pdfc, dgb, p5b, pdfb;
                         gs_eval_R(cc_alpha_c, wo_nm, wi_nm, dgc, p5c, pdfc);
                         gs_eval_R(cc_alpha_b, wo_nm, wi_nm, dgb, p5b, pdfb);
-                        float metallic = mat->metallic;
+                        float metallic = cc_metallic;
                         // Lambert lobe of the dielectric base (lambert.rs:77-120)
                         float lam_f = 0.0f, lam_pdf = 0.0f;
                         if (wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) { lam_f = fabsf(wi_nm.z) / PI_F; lam_pdf = lam_f; }

@@ -389,7 +389,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | (m.roughness >= 1e-3f ? FEAT_ROUGH : 0u);
         if (m.type == MT_CLEARCOAT) features |= FEAT_CC;
         if (m.type == MT_METAL) features |= FEAT_METAL;
-        if (m.normal_tex != 0xffffffffu || m.color.kind == SPK_TEXTURE || m.cc_tint.kind == SPK_TEXTURE) features |= FEAT_TEX;
+        if (m.normal_tex != 0xffffffffu || m.color.kind == SPK_TEXTURE || m.cc_tint.kind == SPK_TEXTURE || m.metallic_tex != 0xffffffffu ||
+            m.roughness_tex != 0xffffffffu) features |= FEAT_TEX;
     }
     info = "nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth);
     built = true;

@@ -48,7 +48,12 @@ class MaterialDesc(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color", Spectrum), ("normal_tex", C.c_uint32), ("normal_flip_y", C.c_uint32),
                 ("intensity", C.c_float), ("eta", Spectrum), ("thin", C.c_uint32), ("roughness", C.c_float),
                 ("metallic", C.c_float), ("ior", C.c_float), ("clearcoat_ior", C.c_float), ("clearcoat_roughness", C.c_float),
-                ("clearcoat_thickness", C.c_float), ("clearcoat_tint", Spectrum), ("k", Spectrum)]
+                ("clearcoat_thickness", C.c_float), ("clearcoat_tint", Spectrum), ("k", Spectrum),
+                ("metallic_tex", C.c_uint32), ("roughness_tex", C.c_uint32)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.metallic_tex = NONE; self.roughness_tex = NONE
 
 
 LIGHT_POINT, LIGHT_SPOT, LIGHT_DIRECTIONAL = 1, 2, 3

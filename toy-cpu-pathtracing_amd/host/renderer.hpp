@@ -301,7 +301,18 @@ struct SpectrumParameter {
     static SpectrumParameter constant(Spectrum s) { SpectrumParameter p; p.spectrum = std::move(s); return p; }
     static SpectrumParameter texture(RgbTexture t, SpectrumType) { SpectrumParameter p; p.is_texture = true; p.tex = std::move(t); return p; }
 };
-struct FloatParameter { float v; static FloatParameter constant(float x) { return {x}; } };
+struct FloatTexture {                                          // texture/float_texture.rs:24-31 (gamma_corrected = false only)
+    std::shared_ptr<ImageRgb8> img;
+    static FloatTexture load(const std::string& p, bool gamma_corrected) {
+        if (gamma_corrected) throw std::runtime_error("FloatTexture: gamma-corrected maps are not supported");
+        return {std::make_shared<ImageRgb8>(load_image(p))};
+    }
+};
+struct FloatParameter {                                        // material/parameter.rs:58-83
+    float v = 0.0f; std::shared_ptr<ImageRgb8> tex;
+    static FloatParameter constant(float x) { FloatParameter p; p.v = x; return p; }
+    static FloatParameter texture(FloatTexture t) { FloatParameter p; p.tex = std::move(t.img); return p; }
+};
 struct NormalParameter {
     bool has = false; NormalTexture tex{};
     static NormalParameter none() { return {}; }
@@ -313,6 +324,7 @@ struct Material {
     uint32_t type = 0; SpectrumParameter color; NormalParameter normal; float intensity = 1; Spectrum eta; bool thin = false; float roughness = 0;
     float metallic = 0, ior = 1.5f, clearcoat_ior = 1.5f, clearcoat_roughness = 0, clearcoat_thickness = 0; SpectrumParameter clearcoat_tint;
     Spectrum k;   // metal: extinction coefficient
+    std::shared_ptr<ImageRgb8> metallic_tex, roughness_tex;   // FloatParameter::texture (grey image replicated to RGB)
 };
 struct LambertMaterial { static Material create(SpectrumParameter albedo, NormalParameter n) { Material m; m.type = MI355PT_MAT_LAMBERT; m.color = std::move(albedo); m.normal = std::move(n); return m; } };
 struct EmissiveMaterial { static Material create(SpectrumParameter radiance, FloatParameter intensity) { Material m; m.type = MI355PT_MAT_EMISSIVE; m.color = std::move(radiance); m.intensity = intensity.v; return m; } };
@@ -331,7 +343,7 @@ struct PlasticMaterial {
 enum class MetalType { Gold, Silver, Copper, Aluminum, Brass };                       // metal_material.rs:16-29
 struct MetalMaterial {                                                                 // metal_material.rs:44-92
     static Material create(MetalType t, NormalParameter n, FloatParameter rough) {
-        Material m; m.type = MI355PT_MAT_METAL; m.normal = std::move(n); m.roughness = rough.v;
+        Material m; m.type = MI355PT_MAT_METAL; m.normal = std::move(n); m.roughness = rough.v; m.roughness_tex = rough.tex;
         m.color = SpectrumParameter::constant(ConstantSpectrum::create(1.0f));
         switch (t) {
             case MetalType::Gold: m.eta = presets::au_eta(); m.k = presets::au_k(); break;
@@ -346,6 +358,7 @@ struct MetalMaterial {                                                          
 struct SimplePbrMaterial {                                                             // simple_pbr_material.rs:29-45
     static Material create(SpectrumParameter base_color, FloatParameter metallic, FloatParameter roughness, NormalParameter n, FloatParameter ior) {
         Material m; m.type = MI355PT_MAT_SIMPLE_PBR; m.color = std::move(base_color); m.metallic = metallic.v; m.roughness = roughness.v;
+        m.metallic_tex = metallic.tex; m.roughness_tex = roughness.tex;
         m.normal = std::move(n); m.ior = ior.v; return m;
     }
 };
@@ -353,6 +366,7 @@ struct SimpleClearcoatPbrMaterial {
     static Material create(SpectrumParameter base_color, FloatParameter metallic, FloatParameter roughness, NormalParameter n, FloatParameter ior,
                            FloatParameter cc_ior, FloatParameter cc_rough, SpectrumParameter cc_tint, FloatParameter cc_thickness) {
         Material m; m.type = MI355PT_MAT_CLEARCOAT; m.color = std::move(base_color); m.metallic = metallic.v; m.roughness = roughness.v; m.normal = std::move(n);
+        m.metallic_tex = metallic.tex; m.roughness_tex = roughness.tex;
         m.ior = ior.v; m.clearcoat_ior = cc_ior.v; m.clearcoat_roughness = cc_rough.v; m.clearcoat_tint = std::move(cc_tint); m.clearcoat_thickness = cc_thickness.v; return m;
     }
 };
@@ -510,7 +524,9 @@ public:
     void create_primitive(const GeometryPrimitive& d) {
         mi355pt_material_desc md{};
         const Material& m = d.surface_material;
-        md.type = m.type; md.color = lower(m.color); md.normal_tex = MI355PT_NONE;
+        md.type = m.type; md.color = lower(m.color); md.normal_tex = MI355PT_NONE; md.metallic_tex = md.roughness_tex = MI355PT_NONE;
+        if (m.metallic_tex) md.metallic_tex = add_tex(*m.metallic_tex);
+        if (m.roughness_tex) md.roughness_tex = add_tex(*m.roughness_tex);
         if (m.normal.has) { md.normal_tex = add_tex(*m.normal.tex.img); md.normal_flip_y = m.normal.tex.flip_y ? 1 : 0; }
         md.intensity = m.intensity; md.thin = m.thin ? 1 : 0; md.roughness = m.roughness;
         if (m.type == MI355PT_MAT_GLASS || m.type == MI355PT_MAT_PLASTIC || m.type == MI355PT_MAT_METAL) md.eta = lower_spectrum(m.eta);

@@ -177,6 +177,19 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         scene.add_instance(g, scene.add_material(d), _translate(-0.5, 0.0, -0.5))
         scene.add_environment_light(1.0, assets.sky_envmap(), scene.add_lut470(p["cie_illum_d6500"]))
         cam = make_camera((-1.5, 0.8, 2.5), (1.5, -0.4, -2.5), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 22:   # not a reference scene: scene 15's material shape — SimplePbr with textured base colour, normal map and
+        # FloatTexture metallic / roughness maps (scene_15.rs:18-60), on the dragon-class hero of scene 17
+        g = scene.add_mesh(_asset("dragon"))
+        albedo, normal = _asset(f"tex{tex_size}")
+        grey = lambda a: np.ascontiguousarray(np.repeat(a[..., None], 3, -1))
+        t_met = scene.add_tex_rgb8(grey(albedo[..., 0]))               # stand-in Metallic.png / Roughness.png (grey, replicated)
+        t_rgh = scene.add_tex_rgb8(grey((albedo[..., 1] // 2 + 40).astype(np.uint8)))
+        d = MaterialDesc(); d.type = MAT_SIMPLE_PBR; d.color = Spectrum.texture_albedo_srgb(scene.add_tex_rgb8(albedo))
+        d.normal_tex = scene.add_tex_rgb8(normal); d.normal_flip_y = 0; d.metallic = 0.0; d.roughness = 0.0; d.ior = 1.5
+        d.metallic_tex = t_met; d.roughness_tex = t_rgh
+        scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
+        _room(scene, p)
+        cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
     elif scene_id == 21:   # not a reference scene: scene 2's room lit by a spot light, a directional light AND the area light
         g = scene.add_mesh(_asset("bunny"))
         scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
