@@ -38,3 +38,46 @@ def test_host_only_entry_points(pkg):
         raise AssertionError("bad material accepted")
     except RuntimeError as e:
         assert "not implemented" in str(e)
+
+
+def test_invalid_inputs_return_error_codes(pkg):
+    """Error behaviour of the boundary: bad ids / sizes / null data are refused with a message (never a crash, never an
+    approximation).  Host-only: nothing here reaches the device."""
+    import numpy as np
+    import pytest
+    f = pkg.ffi
+    prod = pkg.Product()
+    sc = prod.new_scene()
+    with pytest.raises(AssertionError):                                 # LUT of the wrong length (caught by the binding)
+        sc.add_lut470(np.zeros(100, np.float32))
+    lut = sc.add_lut470(np.ones(470, np.float32))
+    with pytest.raises(RuntimeError):                                   # texture id that does not exist
+        d = f.MaterialDesc(); d.type = f.MAT_LAMBERT; d.color = f.Spectrum.constant(0.5); d.normal_tex = 5
+        sc.add_material(d)
+    with pytest.raises(RuntimeError):                                   # RGB albedo before the rgb2spec table is set
+        d = f.MaterialDesc(); d.type = f.MAT_LAMBERT; d.color = f.Spectrum.rgb_albedo_srgb(0.5, 0.2, 0.1); d.normal_tex = f.NONE
+        sc.add_material(d)
+    with pytest.raises(RuntimeError):                                   # emissive radiance cannot be a texture
+        d = f.MaterialDesc(); d.type = f.MAT_EMISSIVE; d.color = f.Spectrum.texture_albedo_srgb(0); d.normal_tex = f.NONE
+        sc.add_material(d)
+    d = f.MaterialDesc(); d.type = f.MAT_LAMBERT; d.color = f.Spectrum.constant(0.5); d.normal_tex = f.NONE
+    mat = sc.add_material(d)
+    tri = dict(pos=np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), nrm=np.array([[0, 0, 1]] * 3, np.float32), uv=None,
+               idx=np.array([[0, 1, 2]], np.uint32), tangent=None)
+    g = sc.add_mesh(tri)
+    with pytest.raises(RuntimeError):                                   # index out of range
+        bad = dict(tri); bad["idx"] = np.array([[0, 1, 7]], np.uint32)
+        sc.add_mesh(bad)
+    with pytest.raises(RuntimeError):                                   # unknown geometry / material ids
+        sc.add_instance(g + 3, mat)
+    with pytest.raises(RuntimeError):
+        sc.add_instance(g, mat + 9)
+    with pytest.raises(RuntimeError):                                   # unknown light kind
+        sc.add_delta_light(9, 1.0, f.Spectrum.lut(lut))
+    with pytest.raises(RuntimeError):                                   # environment map with a bad illuminant id
+        sc.add_environment_light(1.0, np.ones((4, 8, 3), np.float32), lut + 5)
+    sc.add_instance(g, mat)
+    cam = f.make_camera((0, 0, 3), (0, 0, -1), (0, 1, 0), 16, 16)
+    with pytest.raises(RuntimeError) as e:                              # no GPU here: the product refuses, it does not fall back
+        sc.build(cam)
+    assert "HIP device" in str(e.value) or "gfx950" in str(e.value)

@@ -199,6 +199,31 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     assert linear_rmse_u8(qg, qc) <= (0.01 if scene_id != 11 else 0.03)    # a NaN sample blacks out its pixel (`as u8`)
 
 
+@pytest.mark.parametrize("w,h,spp,max_depth,strategy,sampler", [
+    (37, 23, 8, 16, "mis", "sobol"),      # ragged: neither side a multiple of the 8x8 tile, odd log2(spp)
+    (1, 1, 64, 16, "mis", "sobol"),       # a single pixel
+    (9, 130, 2, 16, "nee", "sobol"),      # tall and thin, log2(spp) = 1
+    (64, 48, 1, 16, "pt", "sobol"),       # one sample per pixel
+    (50, 40, 12, 16, "mis", "sobol"),     # spp not a power of two
+    (48, 32, 16, 1, "mis", "sobol"),      # max_depth 1: direct light only
+    (33, 17, 32, 3, "nee", "random"),     # counter-hash sampler on a ragged frame
+])
+def test_edge_case_frames_match_oracle(product, oracle, pkg, w, h, spp, max_depth, strategy, sampler):
+    """Ragged / tiny frames, odd sample counts and depth limits through the render path (tile masking, chunked sample ranges
+    with film atomics, Sobol tables at small digit counts): same image as the oracle (reference metric, RMSE of the 8-bit frames)."""
+    pair = {}
+    for name, be in (("gpu", product), ("cpu", oracle)):
+        sc = be.new_scene()
+        pair[name] = (sc, pkg.scenes.load_scene(sc, 0, w, h))
+    oracle.set_faithful(pair["cpu"][0], False)
+    prm = pkg.make_params(spp, strategy, sampler, max_depth=max_depth)
+    img_g = product.render(pair["gpu"][0], pair["gpu"][1], prm)
+    img_c = oracle.render(pair["cpu"][0], pair["cpu"][1], prm)
+    assert img_g.shape == (h, w, 3) and np.isfinite(img_g).all()
+    assert linear_rmse_u8(product.quantize_u8(img_g), oracle.quantize_u8(img_c)) <= 0.012
+    assert abs(float(img_g.mean()) - float(img_c.mean())) <= 0.01 + 0.02 * float(img_c.mean())
+
+
 def test_shards_tile_the_frame(product, pkg):
     """Multi-GPU decomposition: rendering shard k of N touches only its tiles and the shards sum to the full frame."""
     import ctypes as C
