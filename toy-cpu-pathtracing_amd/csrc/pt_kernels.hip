@@ -153,7 +153,13 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
             bool end_path = false;
             ShadowReq sh{};
             if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
-            if (STATS) ts3 = __builtin_amdgcn_s_memtime();
+            if (STATS) {
+                ts3 = __builtin_amdgcn_s_memtime();
+                // the stamps inside shade_vertex are taken by the lanes that reach them: make them wave-level (first lane that has one)
+                unsigned long long ma = __ballot(tsa != 0ull), mb = __ballot(tsb != 0ull);
+                if (ma) { int l = (int)__ffsll((long long)ma) - 1; tsa = ((unsigned long long)__shfl((uint32_t)(tsa >> 32), l) << 32) | __shfl((uint32_t)tsa, l); }
+                if (mb) { int l = (int)__ffsll((long long)mb) - 1; tsb = ((unsigned long long)__shfl((uint32_t)(tsb >> 32), l) << 32) | __shfl((uint32_t)tsb, l); }
+            }
 #if PT_ANY_DEFERRED
             if (__any(sh.on)) {
                 if (STATS && sh.on) st.w[6]++;
