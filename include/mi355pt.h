@@ -40,7 +40,8 @@ enum {
     MI355PT_SPEC_RGB_ALBEDO_SRGB = 1,     /* RgbAlbedoSpectrum<ColorSrgb>::new(c)   spectrum/rgb_albedo_spectrum.rs (needs the table) */
     MI355PT_SPEC_LUT470 = 2,              /* DenselySampledSpectrum, id from add_lut470 (presets::cie_illum_d6500(), glass_sf11_eta(), ...) */
     MI355PT_SPEC_TEXTURE_ALBEDO_SRGB = 3, /* SpectrumParameter::texture(RgbTexture::load_srgb, SpectrumType::Albedo), id from add_tex_rgb8 */
-    MI355PT_SPEC_SIGMOID = 4              /* explicit sigmoid-polynomial coefficients c0,c1,c2 (rgb_sigmoid_polynomial.rs:179-182) */
+    MI355PT_SPEC_SIGMOID = 4,             /* explicit sigmoid-polynomial coefficients c0,c1,c2 (rgb_sigmoid_polynomial.rs:179-182) */
+    MI355PT_SPEC_RGB_ALBEDO_SRGB_LINEAR = 5 /* RgbAlbedoSpectrum<ColorSrgbLinear>::new(c): the same table, no EOTF inversion */
 };
 typedef struct mi355pt_spectrum {
     uint32_t kind;
@@ -79,6 +80,7 @@ typedef struct mi355pt_material_desc {
      * roughness: texture ids from add_tex_rgb8 (a grey image replicated to RGB; the red channel is read with the same bilinear
      * rule, texture/sampler.rs:81-107), MI355PT_NONE = the constant above.  material/parameter.rs:58-83 */
     uint32_t metallic_tex, roughness_tex;
+    uint32_t clearcoat_thickness_tex;   /* clearcoat only (scene_18.rs:37-42) */
 } mi355pt_material_desc;
 
 /* ---- delta lights: CreatePrimitiveDesc::{PointLightPrimitive, SpotLightPrimitive, DirectionalLightPrimitive}

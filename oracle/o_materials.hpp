@@ -454,6 +454,7 @@ struct MaterialEval {
 struct Clearcoat {
     const Material& m; SS base_color, tint; uint64_t key;
     float metallic, roughness;     // FloatParameter values at the shading point
+    float thickness;
     static float r2a(float r) { return r * r; }                                            // :76-78
     static float diel_r0(float ior) { float r = (ior - 1.0f) / (ior + 1.0f); return r * r; }   // :81-84
     static SS attenuation(SS tint, float thickness, float cos_theta) {                     // :88-107
@@ -516,12 +517,13 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
     MaterialSample ms;
     if (m.type == MAT_CLEARCOAT) {                                           // simple_pbr_clearcoat_material.rs:137-260
         Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
-                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv)};
+                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv),
+                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv)};
         M4 tf = normal_map_transform(m, sp.uv);
         M4 tf_inv = inverse(tf);
         V3 wo_nm = transform_vector3(tf, wo);
         BsdfSample bs;
-        if (m.cc_thickness <= 0.0f) {
+        if (cc.thickness <= 0.0f) {
             if (!cc.sample_base(wo_nm, uc, uv, &bs)) return ms;
             ms.f = bs.f; ms.wi = transform_vector3(tf_inv, bs.wi); ms.pdf = bs.pdf; ms.sample_type = bs.type; ms.is_sampled = true;
             return ms;
@@ -535,7 +537,7 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
         float uc_adj = (uc - fc) / (1.0f - fc);
         if (!cc.sample_base(wo_nm, uc_adj, uv, &bs)) return ms;
         V3 wi_sh = transform_vector3(tf_inv, bs.wi);
-        SS att = Clearcoat::attenuation(cc.tint, m.cc_thickness, wo_nm.z) * Clearcoat::attenuation(cc.tint, m.cc_thickness, wi_sh.z);   // Q14
+        SS att = Clearcoat::attenuation(cc.tint, cc.thickness, wo_nm.z) * Clearcoat::attenuation(cc.tint, cc.thickness, wi_sh.z);   // Q14
         ms.f = bs.f * att; ms.wi = wi_sh; ms.pdf = bs.pdf * (1.0f - fc); ms.sample_type = bs.type; ms.is_sampled = true;
         return ms;
     }
@@ -588,14 +590,15 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
 inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const {
     if (m.type == MAT_CLEARCOAT) {                                           // :261-341
         Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
-                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv)};
+                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv),
+                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv)};
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
-        if (m.cc_thickness <= 0.0f) return cc.eval_base(wo_nm, wi_nm);
+        if (cc.thickness <= 0.0f) return cc.eval_base(wo_nm, wi_nm);
         float fc = cc.coat_weight(wo_nm);
         SS cf = cc.coat().evaluate_R(wo_nm, wi_nm);
         SS sf = cc.eval_base(wo_nm, wi_nm);
-        SS att = Clearcoat::attenuation(cc.tint, m.cc_thickness, wo_nm.z) * Clearcoat::attenuation(cc.tint, m.cc_thickness, wi_nm.z);
+        SS att = Clearcoat::attenuation(cc.tint, cc.thickness, wo_nm.z) * Clearcoat::attenuation(cc.tint, cc.thickness, wi_nm.z);
         return cf * fc + sf * att * (1.0f - fc);
     }
     if (m.type == MAT_METAL) {                                               // metal_material.rs:150-192
@@ -630,10 +633,11 @@ inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo
 inline float MaterialEval::pdf(const Material& m, const Wavelengths& wl, V3 wo, V3 wi, const ShadingPoint& sp) const {
     if (m.type == MAT_CLEARCOAT) {                                           // :342-433
         Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
-                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv)};
+                     scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv),
+                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv)};
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
-        if (m.cc_thickness <= 0.0f) return cc.pdf_base(wo_nm, wi_nm);
+        if (cc.thickness <= 0.0f) return cc.pdf_base(wo_nm, wi_nm);
         float fc = cc.coat_weight(wo_nm);
         return cc.coat().pdf_R(wo_nm, wi_nm) * fc + cc.pdf_base(wo_nm, wi_nm) * (1.0f - fc);
     }

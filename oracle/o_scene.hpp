@@ -28,7 +28,7 @@ struct Material {
     float intensity = 1.0f;        // Emissive FloatParameter::Constant
     Spectrum eta;                  // Glass: LUT spectrum; Plastic: constant; Metal: real part of the index
     Spectrum k;                    // Metal: extinction coefficient (presets::au_k() ...)
-    int metallic_tex = -1, roughness_tex = -1;   // FloatParameter::Texture (grey image in the red channel), -1 = constant
+    int metallic_tex = -1, roughness_tex = -1, cc_thickness_tex = -1;   // FloatParameter::Texture (grey image in the red channel), -1 = constant
     bool thin = false;
     float roughness = 0.0f;
     // clearcoat (simple_pbr_clearcoat_material.rs): filled by the API when type == MAT_CLEARCOAT

@@ -135,9 +135,10 @@ struct Rgb2SpecTable {
         return data[TBL + ((((size_t)m * TBL + zi) * TBL + yi) * TBL + xi) * 3 + k];
     }
     // RgbToSpectrumTable::get for ColorSrgb (gamma-encoded input): invert EOTF then look up.
-    void get_srgb_encoded(const float rgb_enc[3], float c[3]) const {
-        V3 rgb{std::fmax(srgb_eotf_inverse(rgb_enc[0]), 0.0f), std::fmax(srgb_eotf_inverse(rgb_enc[1]), 0.0f),
-               std::fmax(srgb_eotf_inverse(rgb_enc[2]), 0.0f)};
+    void get_srgb_encoded(const float rgb_enc[3], float c[3], bool linear = false) const {
+        // color.invert_eotf(): ColorSrgb inverts the sRGB EOTF, ColorSrgbLinear's is the identity (:96-97)
+        V3 rgb{std::fmax(linear ? rgb_enc[0] : srgb_eotf_inverse(rgb_enc[0]), 0.0f), std::fmax(linear ? rgb_enc[1] : srgb_eotf_inverse(rgb_enc[1]), 0.0f),
+               std::fmax(linear ? rgb_enc[2] : srgb_eotf_inverse(rgb_enc[2]), 0.0f)};
         if (rgb.x == rgb.y && rgb.y == rgb.z) {
             c[0] = 0.0f; c[1] = 0.0f; c[2] = std::log(rgb.x / (1.0f - rgb.x));
             return;

@@ -32,6 +32,9 @@ static bool lower_spectrum(ptoracle_scene* h, const mi355pt_spectrum& in, Spectr
         case MI355PT_SPEC_RGB_ALBEDO_SRGB:
             if (!s.table.valid()) return false;
             out->kind = SPEC_SIGMOID; s.table.get_srgb_encoded(in.c, out->c); return true;   // RgbSigmoidPolynomial::from
+        case MI355PT_SPEC_RGB_ALBEDO_SRGB_LINEAR:
+            if (!s.table.valid()) return false;
+            out->kind = SPEC_SIGMOID; s.table.get_srgb_encoded(in.c, out->c, true); return true;
         case MI355PT_SPEC_LUT470:
             if (in.id >= s.luts.size()) return false;
             out->kind = SPEC_LUT470; out->lut = s.luts[in.id].data(); return true;
@@ -99,7 +102,9 @@ int ptoracle_scene_add_material(ptoracle_scene* s, const mi355pt_material_desc* 
     m.thin = d->thin != 0; m.roughness = d->roughness;
     m.metallic_tex = d->metallic_tex == MI355PT_NONE ? -1 : (int)d->metallic_tex;
     m.roughness_tex = d->roughness_tex == MI355PT_NONE ? -1 : (int)d->roughness_tex;
-    if (m.metallic_tex >= (int)s->scene.textures.size() || m.roughness_tex >= (int)s->scene.textures.size()) return -1;
+    m.cc_thickness_tex = (d->type != MI355PT_MAT_CLEARCOAT || d->clearcoat_thickness_tex == MI355PT_NONE) ? -1 : (int)d->clearcoat_thickness_tex;
+    if (m.metallic_tex >= (int)s->scene.textures.size() || m.roughness_tex >= (int)s->scene.textures.size() ||
+        m.cc_thickness_tex >= (int)s->scene.textures.size()) return -1;
     if (d->type == MI355PT_MAT_METAL) { if (!lower_spectrum(s, d->eta, &m.eta) || !lower_spectrum(s, d->k, &m.k)) return -1; }
     if (d->type == MI355PT_MAT_SIMPLE_PBR) {     // SimplePbrMaterial == the clearcoat material's base layer (thickness 0 takes that path)
         m.type = MAT_CLEARCOAT; m.cc_metallic = d->metallic; m.cc_base_ior = d->ior; m.cc_thickness = 0.0f;

@@ -216,6 +216,16 @@ def bunny_textures(size=1024, seed=5):
     return np.ascontiguousarray(albedo), np.ascontiguousarray(normal)
 
 
+def material_maps(size=1024, seed=9):
+    """Grey Metallic / Roughness / ClearcoatThickness stand-ins (dragon-material/*.png), replicated to RGB8."""
+    rng = np.random.default_rng(seed)
+    met = (_value_noise(size, 3, rng) > 0.5).astype(np.float64) * 0.9 + 0.05
+    rgh = 0.15 + 0.6 * _value_noise(size, 4, rng)
+    thk = 0.2 + 0.7 * _value_noise(size, 3, rng)
+    grey = lambda a: np.ascontiguousarray(np.repeat((np.clip(a, 0, 1) * 255.0 + 0.5).astype(np.uint8)[..., None], 3, -1))
+    return grey(met), grey(rgh), grey(thk)
+
+
 def load_obj_semantics(mesh):
     """What TriangleMesh::load_obj computes on top of raw OBJ arrays
     (geometry/impls/triangle_mesh.rs:154-242): per-triangle tangents when texcoords exist."""

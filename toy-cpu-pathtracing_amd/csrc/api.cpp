@@ -229,7 +229,11 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
     m.normal_tex = d->normal_tex; m.normal_flip_y = d->normal_flip_y; m.thin = d->thin;
     m.intensity = d->intensity; m.roughness = d->roughness; m.metallic = d->metallic; m.ior = d->ior;
     m.cc_ior = d->clearcoat_ior; m.cc_roughness = d->clearcoat_roughness; m.cc_thickness = d->clearcoat_thickness;
-    m.metallic_tex = m.roughness_tex = 0xffffffffu;
+    m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu;
+    if (d->type == MI355PT_MAT_CLEARCOAT && d->clearcoat_thickness_tex != MI355PT_NONE) {
+        if (d->clearcoat_thickness_tex >= im.textures.size()) return fail(MI355PT_E_INVALID, "bad clearcoat thickness texture id");
+        m.cc_thickness_tex = d->clearcoat_thickness_tex;
+    }
     if (d->type == MI355PT_MAT_SIMPLE_PBR || d->type == MI355PT_MAT_CLEARCOAT || d->type == MI355PT_MAT_METAL) {
         if ((d->metallic_tex != MI355PT_NONE && d->metallic_tex >= im.textures.size()) || (d->roughness_tex != MI355PT_NONE && d->roughness_tex >= im.textures.size()))
             return fail(MI355PT_E_INVALID, "bad metallic/roughness texture id");
@@ -276,7 +280,7 @@ int mi355pt_scene_add_delta_light(mi355pt_scene* s, const mi355pt_light_desc* d)
     DevMaterial m{};                        // hidden emissive material: carries the light's spectrum with intensity 1
     std::string err;
     int rc;
-    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = 0xffffffffu; m.intensity = 1.0f;
+    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu; m.intensity = 1.0f;
     if ((rc = im.lower_spectrum(d->spectrum, &m.color, false, &err))) return fail(rc, "light spectrum: " + err);
     im.materials.push_back(m);
     mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.color = d->spectrum; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE;
@@ -295,7 +299,7 @@ int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const
     im.env.rgb.assign(rgb, rgb + (size_t)w * h * 3);
     std::memcpy(im.env.l2w, l2w, sizeof(float) * 16);
     DevMaterial m{};                         // hidden emissive material: the integrated RgbIlluminantSpectrum, filled in at build()
-    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = 0xffffffffu; m.intensity = 1.0f; m.color.kind = SPK_CONSTANT;
+    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu; m.intensity = 1.0f; m.color.kind = SPK_CONSTANT;
     im.materials.push_back(m);
     mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE;
     im.mat_descs.push_back(md);

@@ -91,7 +91,8 @@ struct alignas(16) DevMaterial {
     DevSpectrum eta;       // glass: LUT, plastic: constant
     DevSpectrum cc_tint;   // clearcoat tint; metal: extinction coefficient k
     uint32_t metallic_tex, roughness_tex;   // FloatParameter::Texture ids (red channel), ~0 = use the constants above
-    uint32_t pad1[2];
+    uint32_t cc_thickness_tex;
+    uint32_t pad1;
 };
 static_assert(sizeof(DevMaterial) == 160, "material record");
 

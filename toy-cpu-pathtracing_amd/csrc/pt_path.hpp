@@ -384,7 +384,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
             bool d_thin = false, d_plastic = false;
             float albedo[4] = {0, 0, 0, 0};   // Lambert albedo / clearcoat base colour
             float cc_tint[4] = {1, 1, 1, 1};
-            float cc_fc = 0.0f, cc_alpha_c = 0.0f, cc_alpha_b = 0.0f, cc_r0c = 0.0f, cc_r0d = 0.0f, cc_metallic = 0.0f;
+            float cc_fc = 0.0f, cc_alpha_c = 0.0f, cc_alpha_b = 0.0f, cc_r0c = 0.0f, cc_r0d = 0.0f, cc_metallic = 0.0f, cc_thick = 0.0f;
 
             if (mtype == MT_LAMBERT) {
                 // LambertMaterial::sample (lambert_material.rs:42-97) + NormalizedLambertBsdf (lambert.rs:38-75)
@@ -532,14 +532,15 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
                 DevSpectrum ts = load_spectrum(&mat->cc_tint);
                 eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ts, wl, sf.uv, cc_tint, st);
-                float metallic = mat->metallic; const float thick = mat->cc_thickness;
+                float metallic = mat->metallic; float thick = mat->cc_thickness;
                 float rough_b = mat->roughness;
                 if (FEAT & FEAT_TEX) {                                          // FloatParameter::Texture (parameter.rs:65-72)
                     float t3[3];
                     if (mat->metallic_tex != 0xffffffffu) { bilinear_rgb(sc, mat->metallic_tex, sf.uv, t3); metallic = t3[0]; }
                     if (mat->roughness_tex != 0xffffffffu) { bilinear_rgb(sc, mat->roughness_tex, sf.uv, t3); rough_b = t3[0]; }
+                    if (mat->cc_thickness_tex != 0xffffffffu) { bilinear_rgb(sc, mat->cc_thickness_tex, sf.uv, t3); thick = t3[0]; }
                 }
-                cc_metallic = metallic;
+                cc_metallic = metallic; cc_thick = thick;
                 cc_alpha_c = mat->cc_roughness * mat->cc_roughness;                 // roughness_to_alpha :76-78
                 cc_alpha_b = rough_b * rough_b;
                 { float r = (mat->cc_ior - 1.0f) / (mat->cc_ior + 1.0f); cc_r0c = r * r; }   // compute_dielectric_r0 :81-84
@@ -836,7 +837,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         float frd = cc_r0d + (1.0f - cc_r0d) * schlick_p5(fabsf(wo_nm.z));     // fresnel(wo).average(), scalar r0
                         float pdf_met = pdfb, pdf_die = frd * pdfb + (1.0f - frd) * lam_pdf;
                         float pdf_base = metallic >= 1.0f ? pdf_met : (metallic <= 0.0f ? pdf_die : pdf_met * metallic + pdf_die * (1.0f - metallic));
-                        float thick = mat->cc_thickness;
+                        float thick = cc_thick;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             float f_met = (albedo[i] + (1.0f - albedo[i]) * p5b) * dgb;

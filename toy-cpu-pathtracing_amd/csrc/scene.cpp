@@ -76,11 +76,11 @@ void SceneImpl::release() {
 
 static inline float srgb_eotf_inverse(float c) { return c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f); }
 
-bool SceneImpl::table_lookup_srgb(const float enc[3], float c[3]) const {
+bool SceneImpl::table_lookup_srgb(const float enc[3], float c[3], bool linear) const {
     const int TBL = 64;
     if (table.size() != (size_t)(TBL + 3 * TBL * TBL * TBL * 3)) return false;
     float rgb[3];
-    for (int i = 0; i < 3; ++i) rgb[i] = std::fmax(srgb_eotf_inverse(enc[i]), 0.0f);
+    for (int i = 0; i < 3; ++i) rgb[i] = std::fmax(linear ? enc[i] : srgb_eotf_inverse(enc[i]), 0.0f);   // color.invert_eotf() (:96-97)
     if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) { c[0] = 0; c[1] = 0; c[2] = std::log(rgb[0] / (1.0f - rgb[0])); return true; }
     int mc = 0; float mx = rgb[0];
     if (rgb[1] > mx) { mx = rgb[1]; mc = 1; }
@@ -107,6 +107,9 @@ int SceneImpl::lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, bool
         case MI355PT_SPEC_SIGMOID: out->kind = SPK_SIGMOID; std::memcpy(out->c, in.c, 12); return MI355PT_OK;
         case MI355PT_SPEC_RGB_ALBEDO_SRGB:
             if (!table_lookup_srgb(in.c, out->c)) { *err = "RGB spectrum needs mi355pt_scene_set_rgb2spec first"; return MI355PT_E_INVALID; }
+            out->kind = SPK_SIGMOID; return MI355PT_OK;
+        case MI355PT_SPEC_RGB_ALBEDO_SRGB_LINEAR:
+            if (!table_lookup_srgb(in.c, out->c, true)) { *err = "RGB spectrum needs mi355pt_scene_set_rgb2spec first"; return MI355PT_E_INVALID; }
             out->kind = SPK_SIGMOID; return MI355PT_OK;
         case MI355PT_SPEC_LUT470:
             if (in.id >= luts.size()) { *err = "bad LUT id"; return MI355PT_E_INVALID; }
@@ -390,7 +393,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         if (m.type == MT_CLEARCOAT) features |= FEAT_CC;
         if (m.type == MT_METAL) features |= FEAT_METAL;
         if (m.normal_tex != 0xffffffffu || m.color.kind == SPK_TEXTURE || m.cc_tint.kind == SPK_TEXTURE || m.metallic_tex != 0xffffffffu ||
-            m.roughness_tex != 0xffffffffu) features |= FEAT_TEX;
+            m.roughness_tex != 0xffffffffu || m.cc_thickness_tex != 0xffffffffu) features |= FEAT_TEX;
     }
     info = "nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth);
     built = true;

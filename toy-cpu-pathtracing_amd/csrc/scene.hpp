@@ -58,7 +58,7 @@ struct SceneImpl {
     ~SceneImpl();
     void release();
     // RgbSigmoidPolynomial::from(ColorSrgb) on the host (rgb_sigmoid_polynomial.rs:87-155)
-    bool table_lookup_srgb(const float rgb_encoded[3], float c[3]) const;
+    bool table_lookup_srgb(const float rgb_encoded[3], float c[3], bool linear = false) const;
     int lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, bool allow_texture, std::string* err) const;
     int build(const mi355pt_camera* cam, const float* cmf_xyz /*3*470*/, std::string* err);
 };

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(HERE, "csrc", "libmi355pt.so")   # env override: A/B builds while tuning
 
 NONE = 0xFFFFFFFF
-SPEC_CONSTANT, SPEC_RGB_ALBEDO_SRGB, SPEC_LUT470, SPEC_TEXTURE_ALBEDO_SRGB, SPEC_SIGMOID = 0, 1, 2, 3, 4
+SPEC_CONSTANT, SPEC_RGB_ALBEDO_SRGB, SPEC_LUT470, SPEC_TEXTURE_ALBEDO_SRGB, SPEC_SIGMOID, SPEC_RGB_ALBEDO_SRGB_LINEAR = 0, 1, 2, 3, 4, 5
 MAT_LAMBERT, MAT_EMISSIVE, MAT_GLASS, MAT_PLASTIC, MAT_CLEARCOAT, MAT_METAL, MAT_SIMPLE_PBR = 0, 1, 2, 3, 4, 5, 6
 STRATEGY = {"pt": 0, "nee": 1, "mis": 2}
 SAMPLER = {"random": 0, "sobol": 1}
@@ -36,6 +36,10 @@ class Spectrum(C.Structure):
         return Spectrum(SPEC_RGB_ALBEDO_SRGB, 0, (C.c_float * 3)(r, g, b))
 
     @staticmethod
+    def rgb_albedo_srgb_linear(r, g, b):
+        return Spectrum(SPEC_RGB_ALBEDO_SRGB_LINEAR, 0, (C.c_float * 3)(r, g, b))
+
+    @staticmethod
     def lut(i):
         return Spectrum(SPEC_LUT470, i, (C.c_float * 3)(0, 0, 0))
 
@@ -49,11 +53,11 @@ class MaterialDesc(C.Structure):
                 ("intensity", C.c_float), ("eta", Spectrum), ("thin", C.c_uint32), ("roughness", C.c_float),
                 ("metallic", C.c_float), ("ior", C.c_float), ("clearcoat_ior", C.c_float), ("clearcoat_roughness", C.c_float),
                 ("clearcoat_thickness", C.c_float), ("clearcoat_tint", Spectrum), ("k", Spectrum),
-                ("metallic_tex", C.c_uint32), ("roughness_tex", C.c_uint32)]
+                ("metallic_tex", C.c_uint32), ("roughness_tex", C.c_uint32), ("clearcoat_thickness_tex", C.c_uint32)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
-        self.metallic_tex = NONE; self.roughness_tex = NONE
+        self.metallic_tex = NONE; self.roughness_tex = NONE; self.clearcoat_thickness_tex = NONE
 
 
 LIGHT_POINT, LIGHT_SPOT, LIGHT_DIRECTIONAL = 1, 2, 3

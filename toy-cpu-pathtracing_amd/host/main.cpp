@@ -47,6 +47,15 @@ int main(int argc, char** argv) {
             case 1: load_scene_1(scene, camera); break;
             case 2: load_scene_2(scene, camera); break;
             case 3: load_scene_3(scene, camera); break;
+            case 4: load_scene_4(scene, camera); break;
+            case 5: load_scene_5(scene, camera); break;
+            case 9: load_scene_9(scene, camera); break;
+            case 12: load_scene_12(scene, camera); break;
+            case 13: load_scene_13(scene, camera); break;
+            case 14: load_scene_14(scene, camera); break;
+            case 15: load_scene_15(scene, camera); break;
+            case 16: load_scene_16_18(scene, camera, false); break;
+            case 18: load_scene_16_18(scene, camera, true); break;
             case 6: load_scene_6(scene, camera); break;
             case 7: load_scene_7(scene, camera); break;
             case 11: load_scene_11(scene, camera); break;
@@ -54,7 +63,7 @@ int main(int argc, char** argv) {
             case 10: load_scene_10(scene, camera); break;
             case 17: load_scene_17(scene, camera); break;
             case 19: load_scene_19(scene, camera); break;
-            default: std::fprintf(stderr, "scene %u is outside the MI355X hot-path scope (scenes 0, 1, 2, 3, 6, 7, 8, 10, 11, 17, 19)\n", a.scene); return 2;
+            default: std::fprintf(stderr, "scene %u is outside the MI355X hot-path scope (scenes 0-19)\n", a.scene); return 2;
         }
         std::puts("Start build scene.");                                                // main.rs:103-109
         auto t0 = std::chrono::steady_clock::now();

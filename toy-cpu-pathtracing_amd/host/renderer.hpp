@@ -53,8 +53,10 @@ inline std::string data_dir() {
 struct Spectrum { mi355pt_spectrum s{}; std::vector<float> lut; };   // lut non-empty => registered lazily per scene
 
 struct ColorSrgb { float r, g, b; };
+struct ColorSrgbLinear { float r, g, b; };
 struct RgbAlbedoSpectrum {                                            // spectrum/src/spectrum/rgb_albedo_spectrum.rs:21-27
     static Spectrum create(ColorSrgb c) { Spectrum s; s.s.kind = MI355PT_SPEC_RGB_ALBEDO_SRGB; s.s.c[0] = c.r; s.s.c[1] = c.g; s.s.c[2] = c.b; return s; }
+    static Spectrum create(ColorSrgbLinear c) { Spectrum s; s.s.kind = MI355PT_SPEC_RGB_ALBEDO_SRGB_LINEAR; s.s.c[0] = c.r; s.s.c[1] = c.g; s.s.c[2] = c.b; return s; }
 };
 struct ConstantSpectrum {
     static Spectrum create(float v) { Spectrum s; s.s.kind = MI355PT_SPEC_CONSTANT; s.s.c[0] = v; return s; }
@@ -324,7 +326,7 @@ struct Material {
     uint32_t type = 0; SpectrumParameter color; NormalParameter normal; float intensity = 1; Spectrum eta; bool thin = false; float roughness = 0;
     float metallic = 0, ior = 1.5f, clearcoat_ior = 1.5f, clearcoat_roughness = 0, clearcoat_thickness = 0; SpectrumParameter clearcoat_tint;
     Spectrum k;   // metal: extinction coefficient
-    std::shared_ptr<ImageRgb8> metallic_tex, roughness_tex;   // FloatParameter::texture (grey image replicated to RGB)
+    std::shared_ptr<ImageRgb8> metallic_tex, roughness_tex, clearcoat_thickness_tex;   // FloatParameter::texture (grey image replicated to RGB)
 };
 struct LambertMaterial { static Material create(SpectrumParameter albedo, NormalParameter n) { Material m; m.type = MI355PT_MAT_LAMBERT; m.color = std::move(albedo); m.normal = std::move(n); return m; } };
 struct EmissiveMaterial { static Material create(SpectrumParameter radiance, FloatParameter intensity) { Material m; m.type = MI355PT_MAT_EMISSIVE; m.color = std::move(radiance); m.intensity = intensity.v; return m; } };
@@ -367,7 +369,8 @@ struct SimpleClearcoatPbrMaterial {
                            FloatParameter cc_ior, FloatParameter cc_rough, SpectrumParameter cc_tint, FloatParameter cc_thickness) {
         Material m; m.type = MI355PT_MAT_CLEARCOAT; m.color = std::move(base_color); m.metallic = metallic.v; m.roughness = roughness.v; m.normal = std::move(n);
         m.metallic_tex = metallic.tex; m.roughness_tex = roughness.tex;
-        m.ior = ior.v; m.clearcoat_ior = cc_ior.v; m.clearcoat_roughness = cc_rough.v; m.clearcoat_tint = std::move(cc_tint); m.clearcoat_thickness = cc_thickness.v; return m;
+        m.ior = ior.v; m.clearcoat_ior = cc_ior.v; m.clearcoat_roughness = cc_rough.v; m.clearcoat_tint = std::move(cc_tint); m.clearcoat_thickness = cc_thickness.v;
+        m.clearcoat_thickness_tex = cc_thickness.tex; return m;
     }
 };
 
@@ -527,6 +530,7 @@ public:
         md.type = m.type; md.color = lower(m.color); md.normal_tex = MI355PT_NONE; md.metallic_tex = md.roughness_tex = MI355PT_NONE;
         if (m.metallic_tex) md.metallic_tex = add_tex(*m.metallic_tex);
         if (m.roughness_tex) md.roughness_tex = add_tex(*m.roughness_tex);
+        md.clearcoat_thickness_tex = m.clearcoat_thickness_tex ? add_tex(*m.clearcoat_thickness_tex) : MI355PT_NONE;
         if (m.normal.has) { md.normal_tex = add_tex(*m.normal.tex.img); md.normal_flip_y = m.normal.tex.flip_y ? 1 : 0; }
         md.intensity = m.intensity; md.thin = m.thin ? 1 : 0; md.roughness = m.roughness;
         if (m.type == MI355PT_MAT_GLASS || m.type == MI355PT_MAT_PLASTIC || m.type == MI355PT_MAT_METAL) md.eta = lower_spectrum(m.eta);

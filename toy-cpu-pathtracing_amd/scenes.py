@@ -53,8 +53,14 @@ def _asset(name):
             _ASSET_CACHE[name] = assets.load_obj_semantics(assets.bunny_class())
         elif name == "dragon":
             _ASSET_CACHE[name] = assets.load_obj_semantics(assets.dragon_class())
-        elif name.startswith("tex"):
+        elif name.startswith("tex"):                      # bunny-material-0
             _ASSET_CACHE[name] = assets.bunny_textures(int(name[3:]))
+        elif name.startswith("m1tex"):                    # bunny-material-1 (scene 4)
+            _ASSET_CACHE[name] = assets.bunny_textures(int(name[5:]), seed=6)
+        elif name.startswith("dtex"):                     # dragon-material: BaseColor, Normal
+            _ASSET_CACHE[name] = assets.bunny_textures(int(name[4:]), seed=9)
+        elif name.startswith("dmaps"):                    # dragon-material: Metallic, Roughness, ClearcoatThickness
+            _ASSET_CACHE[name] = assets.material_maps(int(name[5:]))
     return _ASSET_CACHE[name]
 
 
@@ -161,7 +167,7 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         scene.add_delta_light(LIGHT_POINT, 10.0, Spectrum.lut(scene.add_lut470(p["cie_illum_d6500"])), _translate(0.0, 3.0, 0.0))
         cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
     elif scene_id == 19:   # scene_19.rs:17-153: floor + three heroes (SimplePbr, clearcoat, plastic) under an environment light.
-        # Stand-ins: constant metallic/roughness instead of FloatTexture maps, sRGB-encoded plastic colour, synthetic sky.
+        # Stand-ins: constant metallic/roughness instead of FloatTexture maps, synthetic sky.
         room = _asset("room")
         scene.add_instance(scene.add_mesh(room["yuka"]), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
         g = scene.add_mesh(_asset("dragon"))
@@ -172,11 +178,64 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         d.metallic = 1.0; d.roughness = 0.7; d.normal_tex = NONE; d.ior = 1.5; d.clearcoat_ior = 1.5
         d.clearcoat_roughness = 0.01; d.clearcoat_tint = Spectrum.rgb_albedo_srgb(0.7, 0.8, 1.0); d.clearcoat_thickness = 0.8
         scene.add_instance(g, scene.add_material(d), _translate(0.5, 0.0, 0.5))
-        d = MaterialDesc(); d.type = MAT_PLASTIC; d.eta = Spectrum.constant(1.5); d.color = Spectrum.rgb_albedo_srgb(0.66, 0.95, 1.0)
+        d = MaterialDesc(); d.type = MAT_PLASTIC; d.eta = Spectrum.constant(1.5); d.color = Spectrum.rgb_albedo_srgb_linear(0.4, 0.9, 1.0)
         d.normal_tex = NONE; d.thin = 0; d.roughness = 0.0
         scene.add_instance(g, scene.add_material(d), _translate(-0.5, 0.0, -0.5))
         scene.add_environment_light(1.0, assets.sky_envmap(), scene.add_lut470(p["cie_illum_d6500"]))
         cam = make_camera((-1.5, 0.8, 2.5), (1.5, -0.4, -2.5), (0.0, 1.0, 0.0), width, height)
+    elif scene_id in (4, 5):     # scene_4.rs: scene 3 with bunny-material-1; scene_5.rs: grey Lambert + normal map, close-up camera
+        g = scene.add_mesh(_asset("bunny"))
+        if scene_id == 4:
+            albedo, normal = _asset(f"m1tex{tex_size}")
+            col = Spectrum.texture_albedo_srgb(scene.add_tex_rgb8(albedo))
+        else:
+            _, normal = _asset(f"tex{tex_size}")
+            col = Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8)
+        scene.add_instance(g, scene.add_material(lambert(col, scene.add_tex_rgb8(normal))))
+        _room(scene, p)
+        cam = (make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height) if scene_id == 4 else
+               make_camera((0.3, 1.6, 2.8), (0.0, -0.5, -2.0), (0.0, 1.0, 0.0), width, height))
+    elif scene_id in (9, 13):    # scene_9.rs: plastic eta 1.8, not thin; scene_13.rs: eta 1.5, linear-sRGB (0.4, 0.9, 1.0) colour
+        g = scene.add_mesh(_asset("bunny"))
+        d = MaterialDesc(); d.type = MAT_PLASTIC; d.normal_tex = NONE; d.thin = 0; d.roughness = 0.0
+        d.eta = Spectrum.constant(1.8 if scene_id == 9 else 1.5)
+        d.color = Spectrum.constant(1.0) if scene_id == 9 else Spectrum.rgb_albedo_srgb_linear(0.4, 0.9, 1.0)
+        scene.add_instance(g, scene.add_material(d))
+        _room(scene, p)
+        cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id in (12, 14):   # scene_12.rs: four BK7 glass heroes, roughness 0.05..0.75; scene_14.rs: four coloured plastic heroes
+        g = scene.add_mesh(_asset("bunny"))
+        positions = [(-1.3, 0.0, -0.5), (-0.5, 0.0, -0.5), (0.3, 0.0, -0.5), (1.1, 0.0, -0.5)]
+        if scene_id == 12:
+            bk7 = Spectrum.lut(scene.add_lut470(p["glass_bk7_eta"]))
+            specs = [(MAT_GLASS, bk7, Spectrum.constant(1.0), r) for r in (0.05, 0.25, 0.5, 0.75)]
+        else:
+            cols = [(1.0, 0.5, 0.5), (0.5, 1.0, 0.5), (0.5, 0.5, 1.0), (1.0, 0.8, 0.4)]
+            specs = [(MAT_PLASTIC, Spectrum.constant(1.5), Spectrum.rgb_albedo_srgb(*c), r) for c, r in zip(cols, (0.05, 0.1, 0.3, 0.5))]
+        for pos, (mt, eta, col, rough) in zip(positions, specs):
+            d = MaterialDesc(); d.type = mt; d.eta = eta; d.color = col; d.normal_tex = NONE; d.thin = 0; d.roughness = rough
+            m = np.diag(np.array([0.6, 0.6, 0.6, 1.0], dtype=np.float32)); m[:3, 3] = np.array(pos, dtype=np.float32)
+            scene.add_instance(g, scene.add_material(d), m)
+        _room(scene, p)
+        cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id in (15, 16, 18):   # the dragon hero of scene 17 with: SimplePbr + texture maps (scene_15.rs), a near-smooth coat
+        # (clearcoat roughness 0.01, scene_16.rs), the same with a FloatTexture coat thickness (scene_18.rs)
+        g = scene.add_mesh(_asset("dragon"))
+        if scene_id == 15:
+            albedo, normal = _asset(f"dtex{tex_size}")
+            met, rgh, _ = _asset(f"dmaps{tex_size}")
+            d = MaterialDesc(); d.type = MAT_SIMPLE_PBR; d.color = Spectrum.texture_albedo_srgb(scene.add_tex_rgb8(albedo))
+            d.metallic_tex = scene.add_tex_rgb8(met); d.roughness_tex = scene.add_tex_rgb8(rgh)
+            d.normal_tex = scene.add_tex_rgb8(normal); d.normal_flip_y = 0; d.ior = 1.5
+        else:
+            d = MaterialDesc(); d.type = MAT_CLEARCOAT; d.color = Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8)
+            d.metallic = 1.0; d.roughness = 0.7; d.normal_tex = NONE; d.ior = 1.5; d.clearcoat_ior = 1.5
+            d.clearcoat_roughness = 0.01; d.clearcoat_tint = Spectrum.rgb_albedo_srgb(0.7, 0.8, 1.0); d.clearcoat_thickness = 0.8
+            if scene_id == 18:
+                d.clearcoat_thickness_tex = scene.add_tex_rgb8(_asset(f"dmaps{tex_size}")[2])
+        scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
+        _room(scene, p)
+        cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
     elif scene_id == 22:   # not a reference scene: scene 15's material shape — SimplePbr with textured base colour, normal map and
         # FloatTexture metallic / roughness maps (scene_15.rs:18-60), on the dragon-class hero of scene 17
         g = scene.add_mesh(_asset("dragon"))
