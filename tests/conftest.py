@@ -46,6 +46,23 @@ def gamma22_rmse_u8(a_u8, b_u8):
     return float(np.sqrt(np.mean(d * d)))
 
 
+def untonemap(img):
+    """Invert Sensor::to_rgb's display transform: sRGB OETF^-1 then Reinhard^-1 (x = y / (1 - y)) -> linear sRGB radiance."""
+    v = np.asarray(img, dtype=np.float64)
+    lin = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4)
+    return lin / np.maximum(1.0 - lin, 1e-6)
+
+
+def furnace_ratio(img):
+    """Scene 23: mean linear radiance of the ellipsoid's interior pixels over the mean of the background's."""
+    lin = untonemap(img)
+    h, w, _ = lin.shape
+    ys, xs = np.mgrid[0:h, 0:w]
+    obj = ((xs - w / 2) / (0.13 * w)) ** 2 + ((ys - h * 0.47) / (0.2 * h)) ** 2 < 1.0        # well inside the silhouette
+    bg = (xs < 0.12 * w) | (xs > 0.88 * w)
+    return lin[obj].mean(axis=0) / lin[bg].mean(axis=0)
+
+
 def median3(img_u8):
     """imageproc::filter::median_filter(&image, 1, 1) (renderer_consistency_test.rs:155-165): 3x3 median per
     channel with edge replication."""

@@ -106,6 +106,20 @@ def test_pt_nee_mis_consistency(oracle, pkg):
     assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
 
 
+@pytest.mark.parametrize("strategy", ["pt", "nee", "mis"])
+def test_furnace_environment_light(oracle, pkg, strategy):
+    """Energy conservation through the environment-light arms of every strategy (camera miss, light sampling with the 2-D CDF,
+    BSDF-sampled escapes with their MIS weights): a convex Lambert body of albedo 0.5 in a constant sky shows exactly half the
+    sky's radiance (up to the smooth-normal / facet mismatch of the mesh)."""
+    from conftest import furnace_ratio
+    sc = oracle.new_scene()
+    cam = pkg.scenes.load_scene(sc, 23, 64, 48)
+    oracle.set_faithful(sc, False)
+    img = oracle.render(sc, cam, pkg.make_params(128, strategy, "sobol"), threads=8)
+    r = furnace_ratio(img)
+    assert np.all(np.abs(r - 0.5) <= 0.015), r
+
+
 def test_conductor_fresnel_known_answers(oracle, pkg):
     """fresnel_complex (bsdf/conductor.rs:92-124) against the closed forms: normal incidence R = ((n-1)^2+k^2)/((n+1)^2+k^2),
     grazing incidence R = 1, k = 0 reduces to the real dielectric Fresnel; gold is yellow (R(600nm) >> R(450nm))."""

@@ -205,6 +205,46 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     assert linear_rmse_u8(qg, qc) <= tol
 
 
+@pytest.mark.parametrize("strategy", ["pt", "nee", "mis"])
+def test_furnace_environment_light_gpu(product, pkg, strategy):
+    """The furnace property of tests/test_oracle.py on the product (no oracle involved): albedo 0.5 under a constant sky."""
+    from conftest import furnace_ratio
+    sc = product.new_scene()
+    cam = pkg.scenes.load_scene(sc, 23, 256, 192)
+    r = furnace_ratio(product.render(sc, cam, pkg.make_params(256, strategy, "sobol")))
+    assert np.all(np.abs(r - 0.5) <= 0.01), r
+
+
+def test_full_size_properties(product, pkg):
+    """BASELINE configs[1] frame size (1920x1080): size-independent properties of the film path — the eight tile shards of an
+    8-GPU job sum to the single-GPU film, sample ranges compose (indices [0,4) + [4,8) = [0,8) up to float summation order),
+    and the resolve is the documented per-pixel function of the sums."""
+    import torch
+    sc = product.new_scene()
+    W, H = 1920, 1080
+    cam = pkg.scenes.load_scene(sc, 3, W, H, tex_size=256)
+    spp = 1024
+
+    def accum(s0, s1, shard=0, shards=1):
+        a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        product.render_accum_device(sc, cam, pkg.make_params(spp, "mis", "sobol", shard_index=shard, shard_count=shards), s0, s1, a.data_ptr(), None)
+        torch.cuda.synchronize()
+        return a
+    full = accum(0, 8)
+    parts = sum(accum(0, 8, k, 8) for k in range(8))
+    assert torch.equal(parts, full)                                        # disjoint tiles: exact
+    assert bool((full.sum(dim=2) > 0).float().mean() > 0.95)               # (spectral -> RGB sums can be slightly negative)
+    two = accum(0, 4) + accum(4, 8)
+    assert float((two - full).abs().max()) <= 1e-4 * float(full.abs().max())
+    out = torch.empty_like(full)
+    product.film_resolve_device(full.data_ptr(), W * H, 8, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    x = torch.clamp(full / 8.0, min=0.0)
+    y = x / (1.0 + x)
+    ref = torch.where(y <= 0.0031308, 12.92 * y, 1.055 * y.pow(1.0 / 2.4) - 0.055)
+    assert float((out - ref).abs().max()) <= 2e-6
+
+
 @pytest.mark.parametrize("w,h,spp,max_depth,strategy,sampler", [
     (37, 23, 8, 16, "mis", "sobol"),      # ragged: neither side a multiple of the 8x8 tile, odd log2(spp)
     (1, 1, 64, 16, "mis", "sobol"),       # a single pixel

@@ -236,6 +236,12 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
         _room(scene, p)
         cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 23:   # not a reference scene: furnace — a convex Lambert ellipsoid (albedo 0.5 at every wavelength) inside a
+        # constant environment: every object pixel must show 0.5 x the background radiance
+        ell = assets.load_obj_semantics(assets.blob_mesh(64, 57, seed=1, lobes=(1, 0.0, 1.0, 1, 0.0, 1.0), center=(0.0, 0.0, 0.0), scale=1.0, with_uv=False))
+        scene.add_instance(scene.add_mesh(ell), scene.add_material(lambert(Spectrum.constant(0.5))))
+        scene.add_environment_light(1.0, np.ones((8, 16, 3), dtype=np.float32), scene.add_lut470(p["cie_illum_d6500"]))
+        cam = make_camera((0.0, 0.6, 4.0), (0.0, -0.15, -1.0), (0.0, 1.0, 0.0), width, height)
     elif scene_id == 22:   # not a reference scene: scene 15's material shape — SimplePbr with textured base colour, normal map and
         # FloatTexture metallic / roughness maps (scene_15.rs:18-60), on the dragon-class hero of scene 17
         g = scene.add_mesh(_asset("dragon"))
