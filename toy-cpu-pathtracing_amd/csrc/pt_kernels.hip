@@ -160,6 +160,9 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
                 if (ma) { int l = (int)__ffsll((long long)ma) - 1; tsa = ((unsigned long long)__shfl((uint32_t)(tsa >> 32), l) << 32) | __shfl((uint32_t)tsa, l); }
                 if (mb) { int l = (int)__ffsll((long long)mb) - 1; tsb = ((unsigned long long)__shfl((uint32_t)(tsb >> 32), l) << 32) | __shfl((uint32_t)tsb, l); }
             }
+            // a light connection whose contribution is exactly zero (light behind the surface, f == 0) cannot change L whatever the
+            // visibility test says: the production path does not trace it (the canonical-count mode does, like the reference)
+            if (!(STATS && prm.stats_mode == 1u) && sh.on && sh.c[0] == 0.0f && sh.c[1] == 0.0f && sh.c[2] == 0.0f && sh.c[3] == 0.0f) sh.on = false;
 #if PT_ANY_DEFERRED
             if (__any(sh.on)) {
                 if (STATS && sh.on) st.w[6]++;
