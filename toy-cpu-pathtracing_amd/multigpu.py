@@ -25,13 +25,18 @@ def reduce_film(accum, world):
     """The job's single film exchange: sum the rank-local linear films onto rank 0 (tiles are disjoint, so the sum is
     exact: every pixel has one non-zero contributor).  RCCL over xGMI for device tensors, gloo on the CPU."""
     if world > 1:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if accum.is_cuda and dist.get_backend() == "gloo":      # rehearsal on a box with fewer GPUs than ranks: stage through the host
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            accum.copy_(host)
+        else:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
     return accum
 
 
 def max_over_ranks(seconds, world, device):
     if world <= 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
