@@ -939,4 +939,13 @@ PT_DEV void film_add(const Path& P, const DevScene& sc, const DevParams& prm, fl
     }
 }
 
+// the RGB contribution of one finished path (the non-probe arm of film_add below), for the pooled loop's LDS film
+PT_DEV void film_rgb(const Path& P, const DevScene& sc, const DevParams& prm, float& r_out, float& g_out, float& b_out) {
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    PathOut none{nullptr, nullptr, nullptr};
+    film_add<false>(P, sc, prm, ar, ag, ab, none, 0u);
+    r_out = ar; g_out = ag; b_out = ab;
+}
+
+
 }  // namespace pt
