@@ -157,6 +157,14 @@ def main():
                 if pj.get("workload") == wl:
                     roofline["traffic"] = pj.get("hbm_bytes_per_launch")
                     roofline["algorithmic_bytes_per_launch"] = round(bps * launch_samples)
+                    # the working set is cache-resident, so three figures are reported — algorithmic bytes/s (= achieved),
+                    # HBM/fabric bytes/s from the PMC passes, and the L2 (TCC) request rate (128-B lines on gfx950)
+                    roofline["hbm_GBps"] = round(roofline["traffic"] / (avg_ms * 1e-3) / 1e9, 1)
+                    roofline["hbm_frac"] = round(roofline["hbm_GBps"] / PEAK_HBM_GBPS, 5)
+                    if "TCC_HIT_sum_per_launch" in pj:
+                        req = pj["TCC_HIT_sum_per_launch"] + pj["TCC_MISS_sum_per_launch"]
+                        roofline["l2_request_GBps"] = round(req * 128.0 / (avg_ms * 1e-3) / 1e9, 1)
+                        roofline["l2_hit_rate"] = round(pj["TCC_HIT_sum_per_launch"] / req, 4)
             except Exception:
                 pass
         # ---- CPU baseline: the oracle in faithful mode on this box's host cores (rank 0, N=1 only) ----
