@@ -215,6 +215,25 @@ def test_furnace_environment_light_gpu(product, pkg, strategy):
     assert np.all(np.abs(r - 0.5) <= 0.01), r
 
 
+@pytest.mark.parametrize("scene_id", [24, 25])
+def test_degenerate_bvh_scenes(product, oracle, pkg, scene_id):
+    """A scene whose BVH root is a leaf (one triangle) or a single two-triangle leaf: the cooperative traversal starts in a leaf."""
+    pair = {}
+    for name, be in (("gpu", product), ("cpu", oracle)):
+        sc = be.new_scene()
+        pair[name] = (sc, pkg.scenes.load_scene(sc, scene_id, 64, 48))
+    oracle.set_faithful(pair["cpu"][0], False)
+    prm = pkg.make_params(16, "nee", "sobol")
+    img_g = product.render(pair["gpu"][0], pair["gpu"][1], prm)
+    img_c = oracle.render(pair["cpu"][0], pair["cpu"][1], prm)
+    assert img_c.mean() > 0.01 and linear_rmse_u8(product.quantize_u8(img_g), oracle.quantize_u8(img_c)) <= 0.01
+    o = np.zeros((4, 3), np.float32); o[:, 2] = 6.0; o[:, 1] = 1.5
+    d = np.array([[0, 0, -1], [0.05, 0.1, -1], [0.9, 0, -0.1], [-0.2, 0.3, -1]], np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tg = pair["gpu"][0].probe_intersect(o - np.array(pair["gpu"][1].position, np.float32), d)
+    tc = pair["cpu"][0].probe_intersect(o - np.array(pair["cpu"][1].position, np.float32), d)
+    assert np.array_equal(tg[0] > 0, tc[0] > 0) and np.allclose(tg[0], tc[0], rtol=1e-5, atol=1e-6)
+
+
 def test_full_size_properties(product, pkg):
     """BASELINE configs[1] frame size (1920x1080): size-independent properties of the film path — the eight tile shards of an
     8-GPU job sum to the single-GPU film, sample ranges compose (indices [0,4) + [4,8) = [0,8) up to float summation order),

@@ -236,6 +236,15 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
         _room(scene, p)
         cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    elif scene_id in (24, 25):   # not reference scenes: degenerate BVHs — one triangle (the root is a leaf), two triangles (one leaf) under a point light
+        tri = assets.load_obj_semantics(assets.single_triangle())
+        if scene_id == 25:
+            tri2 = dict(tri); tri2["pos"] = (tri["pos"] + np.array([0.5, 0.0, -1.0], dtype=np.float32)).astype(np.float32)
+        scene.add_instance(scene.add_mesh(tri), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.5, 0.5))))
+        if scene_id == 25:
+            scene.add_instance(scene.add_mesh(tri2), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.5, 0.8, 0.5))))
+        scene.add_delta_light(LIGHT_POINT, 10.0, Spectrum.lut(scene.add_lut470(p["cie_illum_d6500"])), _translate(0.5, 2.0, 2.5))
+        cam = make_camera((0.0, 1.5, 6.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), width, height)
     elif scene_id == 23:   # not a reference scene: furnace — a convex Lambert ellipsoid (albedo 0.5 at every wavelength) inside a
         # constant environment: every object pixel must show 0.5 x the background radiance
         ell = assets.load_obj_semantics(assets.blob_mesh(64, 57, seed=1, lobes=(1, 0.0, 1.0, 1, 0.0, 1.0), center=(0.0, 0.0, 0.0), scale=1.0, with_uv=False))
