@@ -234,6 +234,14 @@ def test_degenerate_bvh_scenes(product, oracle, pkg, scene_id):
     assert np.array_equal(tg[0] > 0, tc[0] > 0) and np.allclose(tg[0], tc[0], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("strategy", ["pt", "nee", "mis"])
+def test_scene_without_lights_is_black(product, pkg, strategy):
+    sc = product.new_scene()
+    cam = pkg.scenes.load_scene(sc, 26, 64, 48)
+    img = product.render(sc, cam, pkg.make_params(8, strategy, "sobol"))
+    assert np.array_equal(img, np.zeros_like(img))
+
+
 def test_full_size_properties(product, pkg):
     """BASELINE configs[1] frame size (1920x1080): size-independent properties of the film path — the eight tile shards of an
     8-GPU job sum to the single-GPU film, sample ranges compose (indices [0,4) + [4,8) = [0,8) up to float summation order),

@@ -236,6 +236,10 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
         _room(scene, p)
         cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 26:   # not a reference scene: no light at all (every strategy must return a black frame)
+        scene.add_instance(scene.add_mesh(_asset("bunny")), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        _room(scene, p, with_light=False)
+        cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
     elif scene_id in (24, 25):   # not reference scenes: degenerate BVHs — one triangle (the root is a leaf), two triangles (one leaf) under a point light
         tri = assets.load_obj_semantics(assets.single_triangle())
         if scene_id == 25:
