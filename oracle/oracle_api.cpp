@@ -283,6 +283,21 @@ int ptoracle_probe_rgb2spec(ptoracle_scene* s, const float* rgb_enc, uint32_t n,
     for (uint32_t i = 0; i < n; ++i) s->scene.table.get_srgb_encoded(rgb_enc + 3 * i, out_c + 3 * i);
     return 0;
 }
+// Trowbridge-Reitz probes (bsdf/dielectric.rs:29-112 = conductor.rs:151-250): D(wm), visible-normal density Dw(wo, wm), G(wo, wi)
+// for wm = wi = dirs[i]; sample_wm(wo, u) for the n (u.x, u.y) pairs
+void ptoracle_probe_ggx(float alpha_x, float alpha_y, const float* wo3, const float* dirs, uint32_t n, float* out_D, float* out_Dw, float* out_G) {
+    DielectricBsdf g(SS::one(), true, false, alpha_x, alpha_y);
+    V3 wo{wo3[0], wo3[1], wo3[2]};
+    for (uint32_t i = 0; i < n; ++i) {
+        V3 w{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+        out_D[i] = g.D(w); out_Dw[i] = g.Dw(wo, w); out_G[i] = g.G(wo, w);
+    }
+}
+void ptoracle_probe_ggx_sample(float alpha_x, float alpha_y, const float* wo3, const float* u2, uint32_t n, float* out_wm) {
+    DielectricBsdf g(SS::one(), true, false, alpha_x, alpha_y);
+    V3 wo{wo3[0], wo3[1], wo3[2]};
+    for (uint32_t i = 0; i < n; ++i) { V3 w = g.sample_wm(wo, V2{u2[2 * i], u2[2 * i + 1]}); out_wm[3 * i] = w.x; out_wm[3 * i + 1] = w.y; out_wm[3 * i + 2] = w.z; }
+}
 // fresnel_complex probe (bsdf/conductor.rs:92-124), one wavelength lane replicated
 float ptoracle_probe_fresnel_complex(float cos_i, float eta, float k) { return fresnel_complex(cos_i, SS::constant(eta), SS::constant(k)).v[0]; }
 int ptoracle_bvh_stats(ptoracle_scene* s, uint64_t* out /* tlas nodes, total blas nodes */) {

@@ -89,6 +89,21 @@ class Oracle(ffi.Backend):
         self.lib.ptoracle_sobol_matrices(ffi._ptr(out, C.c_uint32))
         return out
 
+    def ggx(self, alpha_x, alpha_y, wo, dirs):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3); wo = np.ascontiguousarray(wo, dtype=np.float32)
+        n = dirs.shape[0]
+        D, Dw, G = (np.zeros(n, np.float32) for _ in range(3))
+        self.lib.ptoracle_probe_ggx(C.c_float(alpha_x), C.c_float(alpha_y), ffi._ptr(wo, C.c_float), ffi._ptr(dirs, C.c_float), n,
+                                    ffi._ptr(D, C.c_float), ffi._ptr(Dw, C.c_float), ffi._ptr(G, C.c_float))
+        return D, Dw, G
+
+    def ggx_sample(self, alpha_x, alpha_y, wo, u):
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 2); wo = np.ascontiguousarray(wo, dtype=np.float32)
+        out = np.zeros((u.shape[0], 3), np.float32)
+        self.lib.ptoracle_probe_ggx_sample(C.c_float(alpha_x), C.c_float(alpha_y), ffi._ptr(wo, C.c_float), ffi._ptr(u, C.c_float), u.shape[0],
+                                           ffi._ptr(out, C.c_float))
+        return out
+
     def fresnel_complex(self, cos_i, eta, k):
         return float(self.lib.ptoracle_probe_fresnel_complex(cos_i, eta, k))
 

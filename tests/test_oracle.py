@@ -120,6 +120,29 @@ def test_furnace_environment_light(oracle, pkg, strategy):
     assert np.all(np.abs(r - 0.5) <= 0.015), r
 
 
+@pytest.mark.parametrize("alpha", [0.05, 0.25, 0.5625])
+def test_ggx_distribution_properties(oracle, alpha):
+    """Trowbridge-Reitz code shared by the dielectric, conductor and Schlick BSDFs: D is normalised (int D cos = 1), the visible-normal
+    density Dw(wo, .) over the visible normals integrates to 1 for any wo, and sample_wm draws from it (E[h(wm)] under sampling = int h Dw)."""
+    nt, nph = 2000, 512
+    th = (np.arange(nt) + 0.5) / nt * (np.pi / 2); ph = (np.arange(nph) + 0.5) / nph * 2 * np.pi
+    TH, PH = np.meshgrid(th, ph, indexing="ij")
+    dirs = np.stack([np.sin(TH) * np.cos(PH), np.sin(TH) * np.sin(PH), np.cos(TH)], -1).reshape(-1, 3)
+    dw = (np.sin(TH) * (np.pi / 2 / nt) * (2 * np.pi / nph)).reshape(-1)
+    for wo in ([0.0, 0.0, 1.0], [0.6, 0.0, 0.8], [0.3, -0.9, 0.31622777]):
+        D, Dw, _ = oracle.ggx(alpha, alpha, wo, dirs)
+        assert abs(float(np.sum(D.astype(np.float64) * dirs[:, 2] * dw)) - 1.0) <= 0.01
+        # Dw uses |wo . wm| like the reference (dielectric.rs:65-75); the density of the VISIBLE normals keeps wo . wm > 0 only
+        vis = Dw.astype(np.float64) * (dirs @ np.asarray(wo, np.float64) > 0)
+        assert abs(float(np.sum(vis * dw)) - 1.0) <= 0.01
+        rng = np.random.default_rng(3)
+        wm = oracle.ggx_sample(alpha, alpha, wo, rng.random((200000, 2)))
+        assert np.all(np.abs(np.linalg.norm(wm, axis=1) - 1.0) <= 1e-5) and np.all(wm[:, 2] > 0)
+        for h in (lambda w: w[:, 2], lambda w: w[:, 0] * w[:, 0]):          # two test functions
+            expect = float(np.sum(h(dirs) * vis * dw))
+            assert abs(float(h(wm).mean()) - expect) <= 0.01 + 0.01 * abs(expect)
+
+
 def test_conductor_fresnel_known_answers(oracle, pkg):
     """fresnel_complex (bsdf/conductor.rs:92-124) against the closed forms: normal incidence R = ((n-1)^2+k^2)/((n+1)^2+k^2),
     grazing incidence R = 1, k = 0 reduces to the real dielectric Fresnel; gold is yellow (R(600nm) >> R(450nm))."""
