@@ -242,6 +242,32 @@ def test_scene_without_lights_is_black(product, pkg, strategy):
     assert np.array_equal(img, np.zeros_like(img))
 
 
+def test_work_counters_match_oracle(product, oracle, pkg):
+    """the per-sample work counts behind `roofline.achieved` — rays, hits, bounces counted by the instrumented
+    kernel in the reference's traversal order (collect_stats = 1) agree with the instrumented oracle within 2 %; node and
+    triangle counts are of the same order (the oracle walks the reference's two-level BVH, the product its flat one)."""
+    import torch
+    W, H, spp = 256, 192, 16
+    pair = {}
+    for name, be in (("gpu", product), ("cpu", oracle)):
+        sc = be.new_scene()
+        pair[name] = (sc, pkg.scenes.load_scene(sc, 3, W, H, tex_size=256))
+    oracle.set_faithful(pair["cpu"][0], False)
+    st = pkg.ffi.Stats()
+    a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    product.render_accum_device(pair["gpu"][0], pair["gpu"][1], pkg.make_params(spp, "mis", "sobol", collect_stats=1), 0, spp, a.data_ptr(), None, stats=st)
+    g = st.as_dict()
+    oracle.counters(pair["cpu"][0], reset=True)
+    oracle.render_accum(pair["cpu"][0], pair["cpu"][1], pkg.make_params(spp, "mis", "sobol"), 0, spp, threads=8, counters=True)
+    c = oracle.counters(pair["cpu"][0])
+    assert g["samples"] == c["samples"] == W * H * spp
+    for k in ("closest_rays", "shadow_rays", "closest_hits", "bounces"):
+        assert abs(g[k] - c[k]) <= 0.02 * c[k], (k, g[k], c[k])
+    nodes_c = c["closest_tlas_nodes"] + c["closest_blas_nodes"] + c["any_tlas_nodes"] + c["any_blas_nodes"]
+    nodes_g = g["nodes_closest"] + g["nodes_shadow"]
+    assert 0.3 <= nodes_g / nodes_c <= 3.0
+
+
 def test_full_size_properties(product, pkg):
     """BASELINE configs[1] frame size (1920x1080): size-independent properties of the film path — the eight tile shards of an
     8-GPU job sum to the single-GPU film, sample ranges compose (indices [0,4) + [4,8) = [0,8) up to float summation order),
