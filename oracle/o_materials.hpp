@@ -408,19 +408,27 @@ struct GenSchlickBsdf {
         return g.Dw(wo, wm) / jac;
     }
     // directional_albedo (:893-918): 64-sample Monte Carlo of f * |cos_i| / pdf
+    // The 64 terms are summed as a balanced pairwise tree over the sample index (t[i] += t[i ^ 1], ^2, ^4, ...): the order in
+    // which the HIP kernel's 64 lanes combine them with an xor butterfly, so both sides agree bit for bit.
     SS directional_albedo(V3 wo, uint64_t key) const {
-        SS sum = SS::zero();
+        SS term[64];
         McRng rng{key};
         for (int k = 0; k < 64; ++k) {
             float uc = rng.next(); (void)uc;
             V2 uv{0, 0}; uv.x = rng.next(); uv.y = rng.next();
             BsdfSample s;
+            term[k] = SS::zero();
             if (sample_R(wo, uv, &s)) {
                 float ci = std::fabs(s.wi.z);
-                if (ci > 0.0f && s.pdf > 0.0f) sum = sum + s.f * ci / s.pdf;
+                if (ci > 0.0f && s.pdf > 0.0f) term[k] = s.f * ci / s.pdf;
             }
         }
-        return sum / 64.0f;
+        for (int m = 1; m < 64; m <<= 1) {
+            SS next[64];
+            for (int i = 0; i < 64; ++i) next[i] = term[i] + term[i ^ m];
+            for (int i = 0; i < 64; ++i) term[i] = next[i];
+        }
+        return term[0] / 64.0f;
     }
 };
 

@@ -21,7 +21,7 @@ hipError_t launch_probe_sobol(uint32_t, uint32_t, uint32_t, uint32_t, const uint
 hipError_t launch_probe_intersect(const DevScene&, const float*, const float*, uint32_t, float*, uint32_t*, uint32_t*, float*, hipStream_t);
 hipError_t launch_probe_occluded(const DevScene&, const float*, const float*, const float*, uint32_t, uint8_t*, hipStream_t);
 uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed);
-int query_resident_waves();
+int query_resident_waves(uint32_t feat);
 }  // namespace pt
 
 using namespace pt;
@@ -114,10 +114,11 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
 };
 
-int resident_waves() {
-    static int cached = 0;
-    if (!cached) cached = query_resident_waves();
-    return cached;
+int resident_waves(uint32_t feat) {
+    static int cached[256] = {0};
+    int& c = cached[feat & 255u];
+    if (!c) c = query_resident_waves(feat);
+    return c;
 }
 
 DevParams make_params(const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end) {
@@ -334,7 +335,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     uint32_t n_tiles_total = dp.tiles_x * dp.tiles_y;
     uint32_t n_tiles = n_tiles_total > dp.shard_index ? (n_tiles_total - dp.shard_index + dp.shard_count - 1) / dp.shard_count : 0;
     if (n_tiles == 0) return MI355PT_OK;
-    int waves = resident_waves();
+    int waves = resident_waves((stats && p->collect_stats) ? (uint32_t)FEAT_ALL : s->impl.features);   // the instrumented variant is the all-features kernel
     // split the sample range only when there are too few tiles to fill the chip (small images / many shards)
     uint32_t n_samples = s_end - s_begin;
     uint32_t chunks = 1;
@@ -481,7 +482,7 @@ int mi355pt_probe_radiance(const mi355pt_scene* s, const mi355pt_camera* cam, co
     DevBuf<uint32_t> d_xys; DevBuf<float> d_L, d_lam, d_pdf;
     HIP_TRY(d_xys.alloc((size_t)n * 3)); HIP_TRY(d_L.alloc((size_t)n * 4)); HIP_TRY(d_lam.alloc((size_t)n * 4)); HIP_TRY(d_pdf.alloc((size_t)n * 4));
     HIP_TRY(hipMemcpy(d_xys.p, xys, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice));
-    int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)resident_waves());
+    int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)resident_waves((uint32_t)FEAT_ALL));
     HIP_TRY(launch_probe_radiance(s->impl.dev, dc, dp, lc->d_hash, lc->d_counters + slot, d_xys.p, n, d_L.p, d_lam.p, d_pdf.p, grid, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_L, d_L.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));

@@ -121,6 +121,40 @@ PT_DEV void gs_eval_R(float alpha, f3 wo, f3 wi, float& dg, float& p5, float& pd
 // directional_albedo (:893-918): 64-sample Monte Carlo of f * |cos_i| / pdf for a *scalar* r0 (the coat).
 // The reference seeds it from the thread RNG on every call; here it is one counter stream per path vertex (key),
 // shared bit for bit with the oracle (oracle/o_materials.hpp McRng).
+// One term of that estimate: sample k (0..63) of the stream `key` (the k-th triple of draws: uc unused, u, v).
+PT_DEV float coat_albedo_term(float alpha, float r0, f3 wo, uint64_t key, uint32_t k) {
+    uint64_t h1 = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(3u * k + 2u));
+    uint64_t h2 = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(3u * k + 3u));
+    f2 uv = f2{(float)(uint32_t)(h1 >> 40) * 5.9604644775390625e-8f, (float)(uint32_t)(h2 >> 40) * 5.9604644775390625e-8f};
+    GsSample s = gs_sample_R(alpha, wo, uv);
+    float term = 0.0f;
+    if (s.ok) {
+        float ci = fabsf(s.wi.z);
+        float f = (r0 + (1.0f - r0) * s.p5) * s.dg;
+        if (ci > 0.0f && s.pdf > 0.0f) term = f * ci / s.pdf;
+    }
+    return term;
+}
+// Wave-cooperative form (every lane of the wave must call it): for each lane that needs an estimate, the 64 lanes evaluate
+// one sample each of that lane's stream and sum them with a 6-step xor butterfly = the balanced pairwise tree over the sample
+// index (the oracle sums in the same order).  A wave pays 64 samples per requesting lane instead of 64 x 64 whenever any lane
+// asks — with a clearcoat hero covering a fraction of the tile, most of the 64-sample loops used to run for a few lanes only.
+PT_DEV float coat_directional_albedo_coop(bool need, float alpha, float r0, f3 wo, uint64_t key, uint32_t lane) {
+    float result = 0.0f;
+    unsigned long long m = __ballot(need);
+    while (m != 0ull) {
+        const int i = (int)__ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const float a = __shfl(alpha, i), r = __shfl(r0, i);
+        const f3 w = mk3(__shfl(wo.x, i), __shfl(wo.y, i), __shfl(wo.z, i));
+        const uint64_t kk = ((uint64_t)__shfl((uint32_t)(key >> 32), i) << 32) | (uint64_t)__shfl((uint32_t)key, i);
+        float t = coat_albedo_term(a, r, w, kk, lane);
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) t = t + __shfl_xor(t, s);
+        if ((int)lane == i) result = t / 64.0f;
+    }
+    return result;
+}
 PT_DEV float coat_directional_albedo(float alpha, float r0, f3 wo, uint64_t key) {
     float sum = 0.0f;
     uint32_t n = 0;

@@ -37,6 +37,7 @@
 namespace pt {
 
 #ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES_CC 3
 #define PT_MIN_WAVES 4   // 128 VGPRs: measured +26 % over the unconstrained 220-VGPR build (latency hiding beats the spills)
 #endif
 // work item -> lane assignment
@@ -82,7 +83,7 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 #define PT_CLOSEST_COOP 1      // needs PT_ANY_DEFERRED (shares its LDS ring)
 #endif
 template <bool STATS, bool PROBE, uint32_t FEAT>
-__global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
+__global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WAVES)) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, unsigned* __restrict__ work_counter,
                                                 DevStats* __restrict__ stats, const uint32_t* __restrict__ probe_xys, uint32_t n_probe,
                                                 PathOut pout) {
@@ -180,7 +181,16 @@ __global__ __launch_bounds__(64, PT_MIN_WAVES) void pt_kernel(DevScene sc, DevCa
             if (STATS) ts2 = __builtin_amdgcn_s_memtime();
             bool end_path = false;
             ShadowReq sh{};
-            if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
+            if constexpr ((FEAT & FEAT_CC) != 0u) {
+                ShadeCtx C;
+                C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
+                if (active) end_path = shade_vertex_a<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, C);
+                // the coat's 64-sample directional albedo, estimated by the whole wave for the lanes that need it
+                C.cc_fc = coat_directional_albedo_coop(active && C.cont && C.need_cc, C.cc_alpha_c, C.cc_r0c, C.wo_nm, C.mc_key, lane);
+                if (active && C.cont) end_path = shade_vertex_b<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
+            } else {
+                if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
+            }
             if (STATS) {
                 ts3 = __builtin_amdgcn_s_memtime();
                 // the stamps inside shade_vertex are taken by the lanes that reach them: make them wave-level (first lane that has one)
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(64, DYN_WAVES) void probe_intersect_dyn_kernel(DevS
 // ---------------------------------------------------------------------------------------------
 // smallest compiled specialisation covering `feat`
 static uint32_t pick_features(uint32_t feat) {
-    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_CC, FEAT_ALL};
+    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_CC, FEAT_ALL & ~FEAT_CC, FEAT_ALL};
     for (uint32_t s : sets) if ((feat & ~s) == 0u) return s;
     return FEAT_ALL;
 }
@@ -442,6 +452,7 @@ hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& 
         case FEAT_TEX: PT_LAUNCH(FEAT_TEX); break;
         case FEAT_DIEL: PT_LAUNCH(FEAT_DIEL); break;
         case FEAT_CC: PT_LAUNCH(FEAT_CC); break;
+        case FEAT_ALL & ~FEAT_CC: PT_LAUNCH(FEAT_ALL & ~FEAT_CC); break;
         default: PT_LAUNCH(FEAT_ALL); break;
     }
     return hipGetLastError();
@@ -492,12 +503,23 @@ hipError_t launch_probe_occluded(const DevScene& sc, const float* o, const float
 namespace pt {
 uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed) { return murmur_dim_seed(dimension, seed); }
 // resident 64-thread blocks (= waves) of the render kernel on the current device: the persistent grid size
-int query_resident_waves() {
+// resident 64-thread blocks of the kernel specialisation that `feat` selects (the clearcoat kernels run 3 waves per SIMD, the
+// others 4): the persistent grid size
+int query_resident_waves(uint32_t feat) {
     int dev = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 2048;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_ALL>, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+    hipError_t e;
+    switch (pick_features(feat)) {
+        case 0u: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, 0u>, 64, 0); break;
+        case FEAT_TEX: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_TEX>, 64, 0); break;
+        case FEAT_DIEL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_DIEL>, 64, 0); break;
+        case FEAT_CC: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_CC>, 64, 0); break;
+        case FEAT_ALL & ~FEAT_CC: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_ALL & ~FEAT_CC>, 64, 0); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_ALL>, 64, 0); break;
+    }
+    if (e != hipSuccess || per_cu <= 0) per_cu = 8;
     return prop.multiProcessorCount * per_cu;
 }
 }  // namespace pt
