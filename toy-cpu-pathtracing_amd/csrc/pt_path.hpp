@@ -907,7 +907,9 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
 
 // ---- the same vertex in two halves (shade_vertex_a / shade_vertex_b below) for kernels with the clearcoat material: between the
 // halves the wave estimates the coat's directional albedo cooperatively.  Kernels without FEAT_CC use the single function above:
-// carrying the hand-over state across the re-convergence point costs registers (measured: -29 % on scene 3 when forced). ----
+// carrying the hand-over state across the re-convergence point costs registers (measured: -29 % on scene 3 when forced).
+// The two forms must be edited together.  Both are covered on every scene: the per-sample radiance probes run the all-features
+// kernel (the two-halves form), the frame comparisons the scene's own specialisation (single function unless it has a clearcoat). ----
 // What the first half of a vertex (surface, emission, throughput, Russian roulette, frames, BSDF draws) hands to the second half
 // (BSDF sample, light connection).  Between the two the wave estimates the clearcoat's directional albedo cooperatively.
 struct ShadeCtx {
