@@ -13,7 +13,7 @@
 #include "scene.hpp"
 
 namespace pt {
-hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, unsigned*, DevStats*, bool, uint32_t, int, hipStream_t);
+hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, float*, unsigned*, DevStats*, bool, uint32_t, int, hipStream_t);
 hipError_t launch_probe_radiance(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, unsigned*, const uint32_t*, uint32_t, float*,
                                  float*, float*, int, hipStream_t);
 hipError_t launch_resolve(const float*, uint32_t, uint32_t, float*, hipStream_t);
@@ -48,8 +48,10 @@ struct LaunchCtx {
     bool hash_valid = false;
     unsigned* d_counters = nullptr;   // CTX_RING counters
     DevStats* d_stats = nullptr;      // CTX_RING blocks
+    float* d_partial = nullptr;       // per-chunk film tiles of split launches (n_work * 64 * 3 floats), grown on demand;
+    size_t partial_floats = 0;        // reused by consecutive launches: one stream at a time per scene
     int next = 0;
-    ~LaunchCtx() { (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); }
+    ~LaunchCtx() { (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); (void)hipFree(d_partial); }
 };
 struct mi355pt_scene {
     SceneImpl impl;
@@ -339,7 +341,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     // split the sample range only when there are too few tiles to fill the chip (small images / many shards)
     uint32_t n_samples = s_end - s_begin;
     uint32_t chunks = 1;
-    while (n_tiles * chunks < (uint32_t)waves * 4 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 8) chunks *= 2;
+    while (n_tiles * chunks < (uint32_t)waves * 8 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 8) chunks *= 2;
     if (const char* e = getenv("MI355PT_CHUNKS")) { uint32_t c = (uint32_t)atoi(e); if (c >= 1 && c <= n_samples) chunks = c; }   // tuning experiment
     dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
     dp.n_work = n_tiles * chunks;
@@ -354,7 +356,16 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (stats) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
     int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)waves);
-    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, d_counter, d_stats, want_stats, s->impl.features, grid, stream));
+    if (dp.chunks > 1) {
+        const size_t need = (size_t)dp.n_work * 64u * 3u;
+        if (need > lc->partial_floats) {
+            HIP_TRY(hipStreamSynchronize(stream));                 // an earlier launch may still be reading the old buffer
+            (void)hipFree(lc->d_partial); lc->d_partial = nullptr; lc->partial_floats = 0;
+            HIP_TRY(hipMalloc((void**)&lc->d_partial, need * sizeof(float)));
+            lc->partial_floats = need;
+        }
+    }
+    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, lc->d_partial, d_counter, d_stats, want_stats, s->impl.features, grid, stream));
     if (stats) {
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(hipEventSynchronize(e1));

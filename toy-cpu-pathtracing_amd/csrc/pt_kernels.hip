@@ -6,8 +6,8 @@
 //    sample-major to whichever lane needs a new path, so no lane idles while another still has samples of "its" pixel left
 //    (lanes busy at shading 89 % -> 97 % at 64 samples per item, 71 % -> 81 % at 8).  The tile's film is 768 B of LDS updated
 //    with ds_add_f32 and written back once per work item; the hand-out order is a function of the wave's own lock-step
-//    schedule, so frames are bit-identical from run to run (global float atomics only when a small image forces the sample
-//    range of a tile to be split over several work items);
+//    schedule, so frames are bit-identical from run to run (when the sample range of a tile is split over several work items,
+//    each writes its own slot and combine_kernel adds the slots in chunk order: no float atomics on the film);
 //  * waves are persistent: they pull (tile, sample-chunk) work items from a global counter;
 //  * path state never round-trips through HBM: every lane carries its path in registers and
 //    regenerates the next sample of its pixel when the path ends (in-register compaction);
@@ -84,7 +84,7 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 #endif
 template <bool STATS, bool PROBE, uint32_t FEAT>
 __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WAVES)) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm, const uint64_t* __restrict__ dim_hash_tab,
-                                                float* __restrict__ accum, unsigned* __restrict__ work_counter,
+                                                float* __restrict__ accum, float* __restrict__ partial, unsigned* __restrict__ work_counter,
                                                 DevStats* __restrict__ stats, const uint32_t* __restrict__ probe_xys, uint32_t n_probe,
                                                 PathOut pout) {
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
@@ -243,7 +243,12 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             size_t o = ((size_t)job.py * cam.width + job.px) * 3;
             const float fr = s_film[3 * lane], fg = s_film[3 * lane + 1], fb = s_film[3 * lane + 2];
             if (prm.chunks == 1) { accum[o] += fr; accum[o + 1] += fg; accum[o + 2] += fb; }
-            else { atomicAdd(accum + o, fr); atomicAdd(accum + o + 1, fg); atomicAdd(accum + o + 2, fb); }
+            else {
+                // the sample range of this tile is split over several work items: each writes its own slot, combine_kernel adds the
+                // slots to the film in chunk order (no float atomics: frames stay bit-identical from run to run)
+                float* slot = partial + ((size_t)work * 64u + lane) * 3u;
+                slot[0] = fr; slot[1] = fg; slot[2] = fb;
+            }
         }
         __syncthreads();
     }
@@ -430,6 +435,22 @@ __global__ __launch_bounds__(64, DYN_WAVES) void probe_intersect_dyn_kernel(DevS
     }
 }
 
+// adds the per-chunk film tiles of a split launch to the film, in chunk order (one thread per pixel of each tile of the shard)
+__global__ void combine_kernel(DevCamera cam, DevParams prm, const float* __restrict__ partial, float* __restrict__ accum, uint32_t n_tiles) {
+    const uint32_t tile_k = blockIdx.x, lane = threadIdx.x;
+    if (tile_k >= n_tiles) return;
+    const uint32_t tile = prm.shard_index + tile_k * prm.shard_count;
+    const uint32_t px = (tile % prm.tiles_x) * 8u + (lane & 7u), py = (tile / prm.tiles_x) * 8u + (lane >> 3);
+    if (px >= cam.width || py >= cam.height) return;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t c = 0; c < prm.chunks; ++c) {
+        const float* slot = partial + (((size_t)tile_k * prm.chunks + c) * 64u + lane) * 3u;
+        r += slot[0]; g += slot[1]; b += slot[2];
+    }
+    const size_t o = ((size_t)py * cam.width + px) * 3;
+    accum[o] += r; accum[o + 1] += g; accum[o + 2] += b;
+}
+
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (host side, called from api.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -439,14 +460,13 @@ static uint32_t pick_features(uint32_t feat) {
     for (uint32_t s : sets) if ((feat & ~s) == 0u) return s;
     return FEAT_ALL;
 }
-#define PT_LAUNCH(F) hipLaunchKernelGGL((pt_kernel<false, false, F>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_counter, d_stats, nullptr, 0u, po)
-hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const uint64_t* d_hash, float* d_accum,
+#define PT_LAUNCH(F) hipLaunchKernelGGL((pt_kernel<false, false, F>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, nullptr, 0u, po)
+hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const uint64_t* d_hash, float* d_accum, float* d_partial,
                      unsigned* d_counter, DevStats* d_stats, bool stats, uint32_t feat, int grid, hipStream_t stream) {
     PathOut po{nullptr, nullptr, nullptr};
     if (stats) {
-        hipLaunchKernelGGL((pt_kernel<true, false, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_counter, d_stats, nullptr, 0u, po);
-        return hipGetLastError();
-    }
+        hipLaunchKernelGGL((pt_kernel<true, false, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, nullptr, 0u, po);
+    } else
     switch (pick_features(feat)) {
         case 0u: PT_LAUNCH(0u); break;
         case FEAT_TEX: PT_LAUNCH(FEAT_TEX); break;
@@ -455,13 +475,17 @@ hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& 
         case FEAT_ALL & ~FEAT_CC: PT_LAUNCH(FEAT_ALL & ~FEAT_CC); break;
         default: PT_LAUNCH(FEAT_ALL); break;
     }
+    if (prm.chunks > 1) {
+        const uint32_t n_tiles = prm.n_work / prm.chunks;
+        hipLaunchKernelGGL(combine_kernel, dim3(n_tiles), dim3(64), 0, stream, cam, prm, (const float*)d_partial, d_accum, n_tiles);
+    }
     return hipGetLastError();
 }
 #undef PT_LAUNCH
 hipError_t launch_probe_radiance(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const uint64_t* d_hash, unsigned* d_counter,
                                  const uint32_t* d_xys, uint32_t n, float* d_L, float* d_lam, float* d_pdf, int grid, hipStream_t stream) {
     PathOut po{d_L, d_lam, d_pdf};
-    hipLaunchKernelGGL((pt_kernel<false, true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, nullptr, d_counter, nullptr, d_xys, n, po);
+    hipLaunchKernelGGL((pt_kernel<false, true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, nullptr, nullptr, d_counter, nullptr, d_xys, n, po);
     return hipGetLastError();
 }
 hipError_t launch_resolve(const float* d_accum, uint32_t n_values, uint32_t spp, float* d_out, hipStream_t stream) {
