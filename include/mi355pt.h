@@ -164,11 +164,19 @@ int mi355pt_scene_add_delta_light(mi355pt_scene* s, const mi355pt_light_desc* de
  * presets::cie_illum_d6500() (rgb_illuminant_spectrum.rs:28).  Only the rotation of the transform matters. */
 int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const float* rgb, uint32_t width, uint32_t height,
                                         const float local_to_world[16], uint32_t illuminant_lut);
+/* Which builder mi355pt_scene_build uses for the BVH (stands where Bvh::build is, scene/src/bvh.rs:92-230; no reference
+ * counterpart for the choice).  AUTO: host sweep SAH below 131 072 triangles, the GPU binned-SAH builder from there on;
+ * HOST / GPU force one (GPU fails with MI355PT_E_DEVICE rather than substituting the host builder).  The environment
+ * variable MI355PT_BVH_BUILDER=auto|host|gpu overrides the setting.  Closest hits do not depend on the builder
+ * (up to exact ties between triangles). */
+enum { MI355PT_BVH_AUTO = 0, MI355PT_BVH_HOST = 1, MI355PT_BVH_GPU = 2 };
+int mi355pt_scene_set_bvh_builder(mi355pt_scene* s, int mode);
 /* Scene::build(&camera): world->render translation, BVH build, light list; uploads to the current HIP device.
  * scene.rs:64-76 */
 int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam);
 
-/* Diagnostic: "nodes=.. tris=.. depth=.. features=.." of the built scene (no reference counterpart). */
+/* Diagnostic: "nodes=.. tris=.. depth=.. builder=host|gpu bvh_ms=.. bvh_device_ms=.. features=.." of the built scene
+ * (no reference counterpart). */
 int mi355pt_scene_info(const mi355pt_scene* s, char* buf, size_t buf_size);
 
 /* ---------------- rendering ---------------- */

@@ -76,6 +76,9 @@ def test_invalid_inputs_return_error_codes(pkg):
         sc.add_delta_light(9, 1.0, f.Spectrum.lut(lut))
     with pytest.raises(RuntimeError):                                   # environment map with a bad illuminant id
         sc.add_environment_light(1.0, np.ones((4, 8, 3), np.float32), lut + 5)
+    sc.set_bvh_builder("gpu"); sc.set_bvh_builder("auto")
+    fn = sc.b.fn("scene_set_bvh_builder")
+    assert fn(sc.h, 7) == -1                                            # unknown builder mode
     sc.add_instance(g, mat)
     cam = f.make_camera((0, 0, 3), (0, 0, -1), (0, 1, 0), 16, 16)
     with pytest.raises(RuntimeError) as e:                              # no GPU here: the product refuses, it does not fall back

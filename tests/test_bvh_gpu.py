@@ -1,0 +1,138 @@
+"""GPU BVH builder (csrc/bvh_gpu.hip) against the host sweep-SAH builder and the oracle.
+
+A BVH decides only HOW FAST the closest hit is found, never which one (up to exact ties between triangles):
+so the bar is bit-equal hit distances on the same rays from both builders, the oracle's radiance through a GPU-built
+tree, the depth bound of the LDS traversal stack, and a deterministic result."""
+import re
+
+import numpy as np
+import pytest
+
+from conftest import linear_rmse_u8
+
+pytestmark = pytest.mark.gpu
+
+
+def _info(product, sc):
+    s = product.scene_info(sc)
+    return {k: v for k, v in re.findall(r"(\w+)=(\S+)", s)}
+
+
+def _rays(n, seed, origin=(0.0, 0.0, 0.0)):
+    rng = np.random.default_rng(seed)
+    d = np.stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.6, 0.2, n), -np.ones(n)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = np.tile(np.asarray(origin, np.float32), (n, 1))
+    return o, d.astype(np.float32)
+
+
+def _pair(product, pkg, scene_id, w=128, h=96):
+    out = {}
+    for mode in ("host", "gpu"):
+        sc = product.new_scene()
+        sc.set_bvh_builder(mode)
+        out[mode] = (sc, pkg.scenes.load_scene(sc, scene_id, w, h, tex_size=64))
+    return out
+
+
+@pytest.mark.parametrize("scene_id", [0, 3, 8, 10, 17, 19, 21])
+def test_gpu_built_tree_finds_the_same_hits(product, pkg, scene_id):
+    pair = _pair(product, pkg, scene_id)
+    ih, ig = _info(product, pair["host"][0]), _info(product, pair["gpu"][0])
+    assert ih["builder"] == "host" and ig["builder"] == "gpu"
+    assert ih["tris"] == ig["tris"] and int(ig["depth"]) <= 22
+    assert 0.4 * int(ih["nodes"]) <= int(ig["nodes"]) <= int(ig["tris"])
+    o, d = _rays(200000, scene_id)
+    th, inst_h, tri_h, nh = pair["host"][0].probe_intersect(o, d)
+    tg, inst_g, tri_g, ng = pair["gpu"][0].probe_intersect(o, d)
+    assert (th > 0).mean() > 0.5
+    assert np.array_equal(th > 0, tg > 0)
+    # the winning triangle's t is computed by the same code from the same vertices: bit-equal unless two triangles tie
+    assert (th == tg).mean() >= 0.9999, (th == tg).mean()
+    assert np.abs(th - tg).max() <= 1e-5 * max(1.0, float(th.max()))
+    same = (inst_h == inst_g) & (tri_h == tri_g)
+    assert same.mean() >= 0.999, same.mean()
+    # shadow rays: any-hit answers are builder-independent
+    p = (o + d * (np.where(th > 0, th, 1.0) * 0.999)[:, None]).astype(np.float32)
+    rng = np.random.default_rng(7)
+    sd = rng.normal(0, 1.0, p.shape).astype(np.float32)
+    sd /= np.linalg.norm(sd, axis=1, keepdims=True)
+    tm = rng.uniform(0.2, 6.0, p.shape[0]).astype(np.float32)
+    occ_h, occ_g = pair["host"][0].probe_occluded(p, sd, tm), pair["gpu"][0].probe_occluded(p, sd, tm)
+    assert 0.05 < occ_h.mean() < 0.99 and np.array_equal(occ_h, occ_g)
+
+
+@pytest.mark.parametrize("scene_id,strategy", [(3, "mis"), (17, "nee"), (8, "pt")])
+def test_radiance_parity_through_gpu_built_tree(product, oracle, pkg, scene_id, strategy):
+    """Per-sample spectral radiance of the oracle through a GPU-built tree (same bar as test_parity_gpu.py)."""
+    w, h, spp = 128, 96, 64
+    sg = product.new_scene(); sg.set_bvh_builder("gpu")
+    cam_g = pkg.scenes.load_scene(sg, scene_id, w, h, tex_size=64)
+    so = oracle.new_scene()
+    cam_o = pkg.scenes.load_scene(so, scene_id, w, h, tex_size=64)
+    oracle.set_faithful(so, False)
+    rng = np.random.default_rng(5)
+    n = 20000
+    xys = np.stack([rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, spp, n)], 1).astype(np.uint32)
+    prm = pkg.make_params(spp, strategy, "sobol")
+    Lg, lg, pg = sg.probe_radiance(cam_g, prm, xys)
+    Lc, lc, pc = so.probe_radiance(cam_o, prm, xys)
+    assert np.array_equal(lg, lc)
+    close = np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)
+    assert close.mean() >= 0.98, close.mean()
+
+
+def test_frames_agree_and_gpu_build_is_deterministic(product, pkg):
+    pair = _pair(product, pkg, 3, 128, 96)
+    prm = pkg.make_params(32, "mis", "sobol")
+    img_h = product.render(pair["host"][0], pair["host"][1], prm)
+    img_g = product.render(pair["gpu"][0], pair["gpu"][1], prm)
+    assert linear_rmse_u8(product.quantize_u8(img_h), product.quantize_u8(img_g)) <= 2e-3
+    sc2 = product.new_scene(); sc2.set_bvh_builder("gpu")
+    cam2 = pkg.scenes.load_scene(sc2, 3, 128, 96, tex_size=64)
+    i1, i2 = _info(product, pair["gpu"][0]), _info(product, sc2)
+    assert (i1["nodes"], i1["depth"]) == (i2["nodes"], i2["depth"])
+    assert np.array_equal(img_g, product.render(sc2, cam2, prm))
+
+
+@pytest.mark.parametrize("scene_id", [24, 25])
+def test_tiny_scenes_are_refused_by_the_gpu_builder_and_taken_by_auto(product, pkg, scene_id):
+    sc = product.new_scene(); sc.set_bvh_builder("gpu")
+    with pytest.raises(RuntimeError, match="fewer than 8"):
+        pkg.scenes.load_scene(sc, scene_id, 64, 48)
+    sc = product.new_scene(); sc.set_bvh_builder("auto")
+    pkg.scenes.load_scene(sc, scene_id, 64, 48)
+    assert _info(product, sc)["builder"] == "host"
+
+
+def _blob_scene(product, pkg, mode, n_lon, n_bands, coincident=False):
+    m = pkg.assets.load_obj_semantics(pkg.assets.blob_mesh(n_lon, n_bands, seed=3, lobes=(14, 0.30, 8.0, 60, 0.05, 60.0), center=(0.0, 1.2, -1.0), scale=1.0))
+    sc = product.new_scene(); sc.set_rgb2spec(pkg.scenes.srgb_table()); sc.set_bvh_builder(mode)
+    g = sc.add_mesh(m)
+    d = pkg.ffi.MaterialDesc(); d.type = pkg.ffi.MAT_LAMBERT; d.color = pkg.ffi.Spectrum.constant(0.7); d.normal_tex = pkg.ffi.NONE
+    mat = sc.add_material(d)
+    sc.add_instance(g, mat)
+    if coincident:   # the same mesh twice more in the same place: every centroid occurs three times
+        sc.add_instance(g, mat); sc.add_instance(g, mat)
+    pkg.scenes._room(sc, pkg.scenes.presets())
+    cam = pkg.ffi.make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), 320, 180)
+    sc.build(cam)
+    return sc, cam
+
+
+@pytest.mark.parametrize("n_lon,n_bands,coincident", [(512, 257, False), (128, 65, True)])
+def test_large_mesh_gpu_build(product, pkg, n_lon, n_bands, coincident):
+    """262 k triangles (auto mode must pick the GPU builder), and coincident instances (equal centroids: rank splits)."""
+    sh, cam = _blob_scene(product, pkg, "host", n_lon, n_bands, coincident)
+    sg, _ = _blob_scene(product, pkg, "gpu" if coincident else "auto", n_lon, n_bands, coincident)
+    ih, ig = _info(product, sh), _info(product, sg)
+    assert ig["builder"] == "gpu" and int(ig["depth"]) <= 22 and ih["tris"] == ig["tris"]
+    if not coincident:
+        assert float(ig["bvh_ms"]) < float(ih["bvh_ms"])
+    o, d = _rays(100000, 11)
+    th, _, _, _ = sh.probe_intersect(o, d)
+    tg, _, _, _ = sg.probe_intersect(o, d)
+    assert np.array_equal(th > 0, tg > 0) and (th == tg).mean() >= 0.9999
+    prm = pkg.make_params(8, "mis", "sobol")
+    a, b = product.render(sh, cam, prm), product.render(sg, cam, prm)
+    assert linear_rmse_u8(product.quantize_u8(a), product.quantize_u8(b)) <= (0.02 if coincident else 4e-3)

@@ -317,6 +317,12 @@ int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, co
     s->impl.instances.push_back(hi);
     return MI355PT_OK;
 }
+int mi355pt_scene_set_bvh_builder(mi355pt_scene* s, int mode) {
+    if (!s) return fail(MI355PT_E_INVALID, "null argument");
+    if (mode != MI355PT_BVH_AUTO && mode != MI355PT_BVH_HOST && mode != MI355PT_BVH_GPU) return fail(MI355PT_E_INVALID, "unknown BVH builder mode");
+    s->impl.bvh_builder = mode;
+    return MI355PT_OK;
+}
 int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam) {
     if (!s || !cam) return fail(MI355PT_E_INVALID, "null argument");
     std::string err;

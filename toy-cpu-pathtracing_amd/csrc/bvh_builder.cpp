@@ -98,9 +98,14 @@ struct Builder {
 
 }  // namespace
 
-void build_bvh(const std::vector<BuildTri>& tris, BvhOut* out) {
+void bvh_build_config(float* cost_traverse, float* cost_tri, int* leaf_max) {
     if (const char* e = getenv("MI355PT_BVH_COST_TRI")) COST_TRI = (float)atof(e);
     if (const char* e = getenv("MI355PT_BVH_LEAF")) LEAF_MAX = std::max(1, std::min(atoi(e), MAX_LEAF_TRIS));
+    *cost_traverse = COST_TRAVERSE; *cost_tri = COST_TRI; *leaf_max = LEAF_MAX;
+}
+
+void build_bvh(const std::vector<BuildTri>& tris, BvhOut* out) {
+    { float a, b; int c; bvh_build_config(&a, &b, &c); }
     out->nodes.clear(); out->order.clear();
     Builder b{tris, *out, {}, {}};
     b.idx.resize(tris.size());

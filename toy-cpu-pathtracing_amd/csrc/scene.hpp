@@ -27,6 +27,13 @@ struct BvhOut {
 };
 // Sweep-SAH BVH2 over triangle bounds; children boxes stored in the parent (layout.hpp DevNode).
 void build_bvh(const std::vector<BuildTri>& tris, BvhOut* out);
+// SAH constants shared by both builders (env overrides MI355PT_BVH_COST_TRI / MI355PT_BVH_LEAF are for sweeps only)
+void bvh_build_config(float* cost_traverse, float* cost_tri, int* leaf_max);
+// The same contract built on the current HIP device (bvh_gpu.hip): breadth-first binned SAH, one round of launches
+// per level.  Returns false with *err set when it cannot build (n < 8, out of memory, HIP error).
+bool build_bvh_gpu(const std::vector<BuildTri>& tris, BvhOut* out, double* device_ms, std::string* err);
+
+constexpr size_t BVH_GPU_AUTO_TRIS = 1u << 17;   // "auto": scenes from 131 072 triangles on are built on the GPU
 
 struct DeviceBuffers {
     void* ptrs[16] = {nullptr};
@@ -52,6 +59,10 @@ struct SceneImpl {
     std::vector<void*> allocs;
     uint32_t cmf_lut[3] = {0, 0, 0};
     int bvh_depth = 0;
+    int bvh_builder = 0;          // MI355PT_BVH_AUTO / _HOST / _GPU (mi355pt_scene_set_bvh_builder)
+    int bvh_builder_used = 1;     // what build() took
+    double bvh_build_ms = 0.0;    // wall time of the BVH build inside build(); bvh_device_ms: device part of a GPU build
+    double bvh_device_ms = 0.0;
     uint32_t features = FEAT_ALL;   // FEAT_* bits the scene's materials need (kernel specialisation)
     std::string info;
 

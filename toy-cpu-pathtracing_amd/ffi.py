@@ -108,7 +108,7 @@ def _ptr(a, ty):
 # every symbol include/mi355pt.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
-    "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_build", "render", "render_accum_device", "film_resolve_device",
+    "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_set_bvh_builder", "scene_build", "render", "render_accum_device", "film_resolve_device",
     "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "last_error", "version",
 ]
 
@@ -244,6 +244,12 @@ class SceneHandle:
         cols = np.ascontiguousarray(m.T.reshape(-1))
         self.b.check(self.b.fn("scene_add_environment_light")(self.h, intensity, _ptr(rgb, C.c_float), rgb.shape[1], rgb.shape[0],
                                                               _ptr(cols, C.c_float), illuminant_lut), "scene_add_environment_light")
+
+    def set_bvh_builder(self, mode):
+        """mi355pt_scene_set_bvh_builder: "auto" | "host" | "gpu" (product only; the oracle has its own BVH)."""
+        fn = self.b.fn("scene_set_bvh_builder")
+        fn.argtypes = [C.c_void_p, C.c_int]
+        self.b.check(fn(self.h, {"auto": 0, "host": 1, "gpu": 2}[mode]), "scene_set_bvh_builder")
 
     def build(self, cam):
         self.b.check(self.b.fn("scene_build")(self.h, C.byref(cam)), "scene_build")
