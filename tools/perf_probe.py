@@ -23,6 +23,7 @@ ap.add_argument("--sampler", default="sobol")
 ap.add_argument("--tag", default="")
 ap.add_argument("--max-depth", type=int, default=16)
 ap.add_argument("--shards", type=int, default=1, help="render only shard 0 of N (emulates one rank of an N-GPU job)")
+ap.add_argument("--no-stats", action="store_true", help="skip the instrumented launch (PC sampling wants only the production kernel)")
 a = ap.parse_args()
 
 pkg = importlib.import_module("toy-cpu-pathtracing_amd")
@@ -43,6 +44,9 @@ for i in range(a.reps + 1):
     ms.append(st.kernel_ms)
 best = min(ms[1:])
 rate = a.width * a.height * a.slice / a.shards / best / 1e3
+if a.no_stats:
+    print(json.dumps({"tag": a.tag, "scene": a.scene, "Msamples_s": round(rate, 1), "ms": [round(x, 2) for x in ms]}))
+    sys.exit(0)
 prm2 = pkg.make_params(a.spp, a.strategy, a.sampler, collect_stats=2, max_depth=a.max_depth, shard_index=0, shard_count=a.shards)
 st = pkg.ffi.Stats()
 prod.render_accum_device(sc, cam, prm2, 0, a.slice, d_acc.value, None, stats=st)

@@ -344,10 +344,12 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     uint32_t n_tiles = n_tiles_total > dp.shard_index ? (n_tiles_total - dp.shard_index + dp.shard_count - 1) / dp.shard_count : 0;
     if (n_tiles == 0) return MI355PT_OK;
     int waves = resident_waves((stats && p->collect_stats) ? (uint32_t)FEAT_ALL : s->impl.features);   // the instrumented variant is the all-features kernel
-    // split the sample range only when there are too few tiles to fill the chip (small images / many shards)
+    // split the sample range only when there are too few tiles to fill the chip (small images / many shards): about 8 work
+    // items per resident wave, but no chunk under 16 samples (every work item rebuilds its tile's Sobol prefix tables; measured
+    // with tools/chunk_sweep.sh: one shard of 4 / 8 at 1080p is 2.2 % / 0.9 % faster with 16-sample than with 8-sample chunks)
     uint32_t n_samples = s_end - s_begin;
     uint32_t chunks = 1;
-    while (n_tiles * chunks < (uint32_t)waves * 8 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 8) chunks *= 2;
+    while (n_tiles * chunks < (uint32_t)waves * 8 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 16) chunks *= 2;
     if (const char* e = getenv("MI355PT_CHUNKS")) { uint32_t c = (uint32_t)atoi(e); if (c >= 1 && c <= n_samples) chunks = c; }   // tuning experiment
     dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
     dp.n_work = n_tiles * chunks;
