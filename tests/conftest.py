@@ -4,6 +4,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- first: torch ships its own HIP runtime; loading it after libmi355pt.so has initialised the system
+              # one leaves torch.cuda without a device (seen when a test selection made the product the first GPU user)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
