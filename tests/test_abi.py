@@ -68,6 +68,9 @@ def test_invalid_inputs_return_error_codes(pkg):
     with pytest.raises(RuntimeError):                                   # index out of range
         bad = dict(tri); bad["idx"] = np.array([[0, 1, 7]], np.uint32)
         sc.add_mesh(bad)
+    with pytest.raises(RuntimeError, match="non-finite"):               # NaN / inf vertex positions
+        bad = dict(tri); bad["pos"] = tri["pos"].copy(); bad["pos"][1, 2] = np.inf
+        sc.add_mesh(bad)
     with pytest.raises(RuntimeError):                                   # unknown geometry / material ids
         sc.add_instance(g + 3, mat)
     with pytest.raises(RuntimeError):

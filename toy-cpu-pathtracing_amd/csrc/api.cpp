@@ -209,6 +209,8 @@ int mi355pt_scene_add_mesh(mi355pt_scene* s, const float* pos, const float* nrm,
     if (!s || !pos || !nrm || !idx || !out || nv == 0 || nt == 0) return fail(MI355PT_E_INVALID, "bad mesh");
     if ((uv != nullptr) != (tri_tangent != nullptr)) return fail(MI355PT_E_INVALID, "uv and tri_tangent must be given together");
     for (size_t i = 0; i < (size_t)nt * 3; ++i) if (idx[i] >= nv) return fail(MI355PT_E_INVALID, "vertex index out of range");
+    // a non-finite position would poison every box above it in the BVH: refuse it here rather than render garbage
+    for (size_t i = 0; i < (size_t)nv * 3; ++i) if (!std::isfinite(pos[i])) return fail(MI355PT_E_INVALID, "non-finite vertex position");
     HostMesh m; m.n_vert = nv; m.n_tri = nt;
     m.pos.assign(pos, pos + (size_t)nv * 3);
     m.nrm.resize((size_t)nv * 3);

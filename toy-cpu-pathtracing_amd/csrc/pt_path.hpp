@@ -218,9 +218,6 @@ PT_DEV void regen_path(Path& P, const SamplerCtx& sctx, const DevCamera& cam, ui
 // One path vertex: the closest-hit result of P.ro/P.rd arrives (got/hit).  Accounts emission (with the strategy's weight),
 // applies throughput + Russian roulette, samples the BSDF and the light.  Returns true when the path ends here; otherwise
 // P.ro/P.rd hold the next ray.  `sh` receives the light connection (it may be set even when the path ends).
-// One path vertex: the closest-hit result of P.ro/P.rd arrives (got/hit).  Accounts emission (with the strategy's weight),
-// applies throughput + Russian roulette, samples the BSDF and the light.  Returns true when the path ends here; otherwise
-// P.ro/P.rd hold the next ray.  `sh` receives the light connection (it may be set even when the path ends).
 template <bool STATS, uint32_t FEAT>
 PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, bool got, const Hit& hit, ShadowReq& sh,
                          StatCounters& st, unsigned long long& tsa, unsigned long long& tsb) {
