@@ -3,14 +3,16 @@
 
 Workload (BASELINE.json configs[1]): scene3 (textured + normal-mapped Lambert hero in the Cornell room, synthetic
 stand-in assets), MIS + ZSobol, 1920x1080, target 1024 spp.  One *step* = one pass of the hot path over one batch =
-the whole 1920x1080 frame for `--spp-per-step` consecutive Sobol sample indices of the 1024-spp job (sample indices
-are per (pixel, sample), so 16 steps of 64 compose exactly the 1024-spp image).  Inputs (BVH, triangles, materials,
-LUTs, tables, textures) are resident in HBM before the timed region; the film accumulators stay in HBM.
+what one `RendererImage::render()` call of the reference does: the whole 1920x1080 frame at all 1024 sample indices of
+the job, into a zeroed film (132.7 M pixel-samples x 16; `--spp-per-step S` < spp splits the job into consecutive
+ranges of S sample indices per step instead, e.g. progressive refinement; jobs above 1024 spp always use ranges of 1024).
+Inputs (BVH, triangles, materials, LUTs, tables, textures) are resident in HBM before the timed region; the film
+accumulators stay in HBM.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's 8x8 pixel tiles are dealt round-robin to
-the ranks (scene replicated); every step each rank renders its own tiles into its own linear film, with no data-path
-collective, and after the K-th step the films are summed onto rank 0 with ONE RCCL reduce over xGMI, inside the timed
-region (strong scaling: the frame is fixed).
+the ranks (scene replicated); each rank renders its own tiles into its own linear film, with no data-path collective,
+and when a frame's last sample index is done the films are summed onto rank 0 with ONE RCCL reduce over xGMI, inside
+the timed region (strong scaling: the frame is fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -44,7 +46,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=0, help="sample indices per step; 0 = the whole job, at most 1024")
     ap.add_argument("--scene", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -84,8 +86,9 @@ def main():
     cam = pkg.scenes.load_scene(scene, args.scene, args.width, args.height)     # BVH build + upload to this rank's GPU
     W, H = args.width, args.height
     spp_job = args.spp
-    sps = args.spp_per_step
+    sps = args.spp_per_step if args.spp_per_step > 0 else min(spp_job, 1024)
     n_slices = max(spp_job // sps, 1)
+    frame_per_step = n_slices == 1      # every step is a complete frame: zeroed film in, reduced film out
 
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -97,11 +100,15 @@ def main():
 
     def step(i, events=None):
         # this rank's tiles for the step's sample indices, added into the rank-local linear film (no collective)
+        if frame_per_step:
+            accum.zero_()
         if events:
             events[0].record()
         mg.render_frame_sharded(render_slice(i % n_slices), accum, rank, world, reduce=False)
         if events:
             events[1].record()       # brackets exactly the path-tracing launch on the stream it was launched on
+        if frame_per_step:
+            mg.reduce_film(accum, world)     # the frame's single film reduce (linear sums, pre-tonemap)
 
     def barrier():
         if world > 1:
@@ -116,7 +123,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, ev[i])
-    mg.reduce_film(accum, world)     # the job's single film reduce (linear sums, pre-tonemap), timed
+    if not frame_per_step:
+        mg.reduce_film(accum, world)     # the job's single film reduce (linear sums, pre-tonemap), timed
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]

@@ -40,7 +40,8 @@ prm = pkg.make_params(a.spp, a.strategy, a.sampler, max_depth=a.max_depth, shard
 ms = []
 for i in range(a.reps + 1):
     st = pkg.ffi.Stats()
-    prod.render_accum_device(sc, cam, prm, i * a.slice, (i + 1) * a.slice, d_acc.value, None, stats=st)
+    k = i % max(a.spp // a.slice, 1)
+    prod.render_accum_device(sc, cam, prm, k * a.slice, (k + 1) * a.slice, d_acc.value, None, stats=st)
     ms.append(st.kernel_ms)
 best = min(ms[1:])
 rate = a.width * a.height * a.slice / a.shards / best / 1e3

@@ -48,7 +48,7 @@ struct LaunchCtx {
     bool hash_valid = false;
     unsigned* d_counters = nullptr;   // CTX_RING counters
     DevStats* d_stats = nullptr;      // CTX_RING blocks
-    float* d_partial = nullptr;       // per-chunk film tiles of split launches (n_work * 64 * 3 floats), grown on demand;
+    float* d_partial = nullptr;       // per-chunk film tiles of split launches (tiles * chunks * 64 * 3 floats), grown on demand;
     size_t partial_floats = 0;        // reused by consecutive launches: one stream at a time per scene
     int next = 0;
     ~LaunchCtx() { (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); (void)hipFree(d_partial); }
@@ -346,15 +346,31 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     uint32_t n_tiles = n_tiles_total > dp.shard_index ? (n_tiles_total - dp.shard_index + dp.shard_count - 1) / dp.shard_count : 0;
     if (n_tiles == 0) return MI355PT_OK;
     int waves = resident_waves((stats && p->collect_stats) ? (uint32_t)FEAT_ALL : s->impl.features);   // the instrumented variant is the all-features kernel
-    // split the sample range only when there are too few tiles to fill the chip (small images / many shards): about 8 work
-    // items per resident wave, but no chunk under 16 samples (every work item rebuilds its tile's Sobol prefix tables; measured
-    // with tools/chunk_sweep.sh: one shard of 4 / 8 at 1080p is 2.2 % / 0.9 % faster with 16-sample than with 8-sample chunks)
+    // Work items.  A work item is a 2^b x 2^b pixel block of an 8x8 tile times a range of sample indices, its (pixel, sample)
+    // pairs handed to the lanes as a pool.  Sobol: the fewer pixels an item has, the fewer Morton digits vary inside it, and only
+    // varying digits (minus the two that have block-level tables) are hashed per draw (pt_device.hpp sampler_index): take the
+    // smallest block that still gives the pool >= PT_MIN_ITEM_SAMPLES pairs, so lanes keep finding new paths and the
+    // per-item prefix tables stay amortised.
     uint32_t n_samples = s_end - s_begin;
+    uint32_t block_log2 = 3;
+    uint64_t PT_MIN_ITEM_SAMPLES = 2048;
+    if (const char* e = getenv("MI355PT_MIN_ITEM")) PT_MIN_ITEM_SAMPLES = (uint64_t)std::max(64, atoi(e));   // tuning experiment
+    if (dp.sampler == MI355PT_SAMPLER_SOBOL) {
+        while (block_log2 > 0 && ((uint64_t)n_samples << (2u * (block_log2 - 1u))) >= PT_MIN_ITEM_SAMPLES) --block_log2;
+    }
+    if (const char* e = getenv("MI355PT_BLOCK")) { int b = atoi(e); if (b >= 0 && b <= 3) block_log2 = (uint32_t)b; }   // tuning experiment
+    // the block-uniform digits are packed into 27 bits of a u32 Morton index: their first bit must be >= 6
+    while (block_log2 < 3 && 2u * ((dp.log2_spp + 1u) / 2u + block_log2) - (dp.log2_spp & 1u) < 6u) ++block_log2;
+    dp.block_log2 = block_log2;
+    const uint32_t n_items = n_tiles * (64u >> (2u * block_log2));
+    // split the sample range only when there are too few items to fill the chip (small images / many shards): about 8 work
+    // items per resident wave, but no chunk under 16 samples (every work item rebuilds its Sobol prefix tables; measured
+    // with tools/chunk_sweep.sh: one shard of 4 / 8 at 1080p is 2.2 % / 0.9 % faster with 16-sample than with 8-sample chunks)
     uint32_t chunks = 1;
-    while (n_tiles * chunks < (uint32_t)waves * 8 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 16) chunks *= 2;
+    while (n_items * chunks < (uint32_t)waves * 8 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 16) chunks *= 2;
     if (const char* e = getenv("MI355PT_CHUNKS")) { uint32_t c = (uint32_t)atoi(e); if (c >= 1 && c <= n_samples) chunks = c; }   // tuning experiment
     dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
-    dp.n_work = n_tiles * chunks;
+    dp.n_work = n_items * chunks;
     LaunchCtx* lc; int slot;
     if ((rc = get_launch_ctx(s, p->seed, stream, &lc, &slot))) return rc;
     unsigned* d_counter = lc->d_counters + slot;
@@ -367,7 +383,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     if (stats) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
     int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)waves);
     if (dp.chunks > 1) {
-        const size_t need = (size_t)dp.n_work * 64u * 3u;
+        const size_t need = (size_t)n_tiles * dp.chunks * 64u * 3u;   // one slot per 8x8 tile and chunk, whatever the block size
         if (need > lc->partial_floats) {
             HIP_TRY(hipStreamSynchronize(stream));                 // an earlier launch may still be reading the old buffer
             (void)hipFree(lc->d_partial); lc->d_partial = nullptr; lc->partial_floats = 0;
@@ -496,7 +512,7 @@ int mi355pt_probe_radiance(const mi355pt_scene* s, const mi355pt_camera* cam, co
     if (n == 0) return MI355PT_OK;
     DevCamera dc = make_camera(cam);
     DevParams dp = make_params(cam, p, 0, p->spp);
-    dp.chunks = 1; dp.chunk_size = 1; dp.n_work = (n + 63) / 64;
+    dp.chunks = 1; dp.chunk_size = 1; dp.block_log2 = 3; dp.n_work = (n + 63) / 64;
     LaunchCtx* lc; int slot;
     if ((rc = get_launch_ctx(s, p->seed, nullptr, &lc, &slot))) return rc;
     HIP_TRY(hipMemset(lc->d_counters + slot, 0, sizeof(unsigned)));

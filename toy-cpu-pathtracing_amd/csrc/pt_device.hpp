@@ -136,12 +136,13 @@ struct SamplerCtx {
     uint32_t hi_shift;            // bit position of that digit
     const uint32_t* p6_lds;       // per dimension: the permutation indices of digit hi_first-2 for the four values of digit hi_first-1
 };
-// The pixels of an aligned 8x8 tile share every Morton digit above the lowest three, and a digit's permutation
+// The pixels of an aligned 8x8 tile share every Morton digit above the lowest three (2^b x 2^b block: the lowest b), and a digit's permutation
 // only depends on the digits above it and on the dimension (:134-145): for those digits the permuted prefix of the
 // sample index is a function of (tile, dimension) alone.  It is computed once per tile and dimension by one lane.
-PT_DEV uint32_t sobol_hi_first(uint32_t log2_spp) { return (log2_spp + 1u) / 2u + 3u; }
-PT_DEV uint64_t sobol_tile_hi_digits(uint32_t tile_morton_shifted, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits) {
-    const uint32_t first = sobol_hi_first(log2_spp);
+// `block_log2`: the work item's pixels form an aligned 2^b x 2^b block, so they share every Morton digit above the lowest b.
+PT_DEV uint32_t sobol_hi_first(uint32_t log2_spp, uint32_t block_log2) { return (log2_spp + 1u) / 2u + block_log2; }
+PT_DEV uint64_t sobol_tile_hi_digits(uint32_t tile_morton_shifted, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits, uint32_t block_log2) {
+    const uint32_t first = sobol_hi_first(log2_spp, block_log2);
     uint64_t out = 0;
     const bool pow2 = (log2_spp & 1u) != 0;
     const uint64_t dmix = 0x55555555ull * (uint64_t)dimension;

@@ -50,11 +50,15 @@ PT_DEV LaneJob lane_job(uint32_t work, uint32_t lane, const DevCamera& cam, cons
         j.valid = qi < n_probe;
         if (j.valid) { j.px = probe_xys[3 * qi]; j.py = probe_xys[3 * qi + 1]; j.s_cur = probe_xys[3 * qi + 2]; j.s_end = j.s_cur + 1; }
     } else {
-        uint32_t tile_k = work / prm.chunks, chunk = work % prm.chunks;
+        // work = ((tile * blocks per tile) + block) * chunks + chunk; lanes >= 4^b own no pixel of the block
+        const uint32_t b = prm.block_log2, bside = 1u << b;
+        uint32_t item = work / prm.chunks, chunk = work % prm.chunks;
+        uint32_t tile_k = item >> (6u - 2u * b), blk = item & ((64u >> (2u * b)) - 1u);
         uint32_t tile = prm.shard_index + tile_k * prm.shard_count;
         uint32_t tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
-        j.px = tx * 8 + (lane & 7); j.py = ty * 8 + (lane >> 3);
-        j.valid = j.px < cam.width && j.py < cam.height;
+        uint32_t bx = blk & ((8u >> b) - 1u), by = blk >> (3u - b);
+        j.px = tx * 8 + bx * bside + (lane & (bside - 1u)); j.py = ty * 8 + by * bside + ((lane >> b) & (bside - 1u));
+        j.valid = lane < (1u << (2u * b)) && j.px < cam.width && j.py < cam.height;
         j.s_cur = prm.sample_begin + chunk * prm.chunk_size;
         j.s_end = min(j.s_cur + prm.chunk_size, prm.sample_end);
     }
@@ -120,13 +124,14 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         // this lane's own pixel of the tile (film write-back) and the work item's wave-uniform sample range
         const LaneJob job = lane_job<PROBE>(work, lane, cam, prm, probe_xys, n_probe);
         const LaneJob job0 = lane_job<PROBE>(work, 0u, cam, prm, probe_xys, n_probe);
-        if (!PROBE && prm.sampler == 1u && sobol_hi_first(prm.log2_spp) < prm.n_base4_digits) {
-            // tile-uniform Sobol digit prefixes: lane d computes dimension d for this tile (lane 0's pixel is the tile origin)
-            sctx.hi_first = sobol_hi_first(prm.log2_spp);
+        const uint32_t blk_log2 = PROBE ? 3u : prm.block_log2, blk_mask = (1u << blk_log2) - 1u;
+        if (!PROBE && prm.sampler == 1u && sobol_hi_first(prm.log2_spp, blk_log2) < prm.n_base4_digits) {
+            // block-uniform Sobol digit prefixes: lane d computes dimension d for this block (lane 0's pixel is the block origin)
+            sctx.hi_first = sobol_hi_first(prm.log2_spp, blk_log2);
             sctx.hi_shift = 2u * sctx.hi_first - (prm.log2_spp & 1u);
             const uint32_t tile_m = encode_morton2_u32(job0.px, job0.py) << prm.log2_spp;
             for (uint32_t dmn = lane; dmn < (uint32_t)SOBOL_HI_DIMS; dmn += 64) {
-                uint32_t e = (uint32_t)(sobol_tile_hi_digits(tile_m, dmn, prm.log2_spp, prm.n_base4_digits) >> sctx.hi_shift);   // <= 26 bits: the Morton index is a u32 and hi_shift >= 6
+                uint32_t e = (uint32_t)(sobol_tile_hi_digits(tile_m, dmn, prm.log2_spp, prm.n_base4_digits, blk_log2) >> sctx.hi_shift);   // <= 26 bits: the Morton index is a u32 and hi_shift >= 6
                 const uint64_t prefix = (uint64_t)tile_m >> sctx.hi_shift;                 // the digits above digit hi_first-1
                 e |= sobol_perm_index(prefix, dmn) << 27;
                 uint32_t e6 = 0;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         s_film[3 * lane] = 0.0f; s_film[3 * lane + 1] = 0.0f; s_film[3 * lane + 2] = 0.0f;
         __syncthreads();
         const uint32_t n_s = PROBE ? 1u : (job0.s_end > job0.s_cur ? job0.s_end - job0.s_cur : 0u);
-        const uint32_t pool_size = 64u * n_s;
+        const uint32_t pool_size = n_s << (2u * blk_log2);
         uint32_t pool_next = 0u;                                   // wave-uniform
         uint32_t my_pix = lane;
         Path P{};
@@ -153,15 +158,15 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             if (m_needy != 0ull && pool_next < pool_size) {
                 const uint32_t idx = pool_next + (uint32_t)__popcll(m_needy & ((1ull << lane) - 1ull));
                 if (!active && idx < pool_size) {
-                    const uint32_t pix = idx & 63u;
+                    const uint32_t pix = idx & ((1u << (2u * blk_log2)) - 1u);
                     uint32_t px, py, smp_i; bool valid;
                     if (PROBE) {
                         const uint32_t qi = work * 64u + pix;
                         valid = qi < n_probe;
                         px = valid ? probe_xys[3 * qi] : 0u; py = valid ? probe_xys[3 * qi + 1] : 0u; smp_i = valid ? probe_xys[3 * qi + 2] : 0u;
                     } else {
-                        px = job0.px + (pix & 7u); py = job0.py + (pix >> 3);
-                        smp_i = job0.s_cur + (idx >> 6);
+                        px = job0.px + (pix & blk_mask); py = job0.py + (pix >> blk_log2);
+                        smp_i = job0.s_cur + (idx >> (2u * blk_log2));
                         valid = px < cam.width && py < cam.height;
                     }
                     if (valid) { active = true; my_pix = pix; regen_path<STATS>(P, sctx, cam, px, py, smp_i, st); }
@@ -246,7 +251,9 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             else {
                 // the sample range of this tile is split over several work items: each writes its own slot, combine_kernel adds the
                 // slots to the film in chunk order (no float atomics: frames stay bit-identical from run to run)
-                float* slot = partial + ((size_t)work * 64u + lane) * 3u;
+                // (slots are laid out per 8x8 tile and chunk whatever the block size, see combine_kernel)
+                const uint32_t tile_k = (work / prm.chunks) >> (6u - 2u * blk_log2), chunk = work % prm.chunks;
+                float* slot = partial + (((size_t)tile_k * prm.chunks + chunk) * 64u + ((job.py & 7u) * 8u + (job.px & 7u))) * 3u;
                 slot[0] = fr; slot[1] = fg; slot[2] = fb;
             }
         }
