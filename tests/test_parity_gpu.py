@@ -336,6 +336,42 @@ def test_shards_tile_the_frame(product, pkg):
     assert np.array_equal(sum(parts), full)
 
 
+@pytest.mark.parametrize("scene_id,w,h,spp", [(3, 160, 104, 1024), (8, 100, 70, 256), (0, 64, 48, 4096)])
+def test_launch_shape_does_not_change_the_frame(product, oracle, pkg, scene_id, w, h, spp):
+    """The launcher picks the work-item shape from the number of sample indices per launch (8x8 tiles for short launches,
+    4x4 / 2x2 / 1x1 pixel blocks for longer ones, api.cpp): the film of the whole job in ONE launch must equal the film
+    accumulated over launches of 64 (and of 16) sample indices up to float summation order, shards included, and must match
+    the oracle's frame like any other."""
+    import torch
+    sc = product.new_scene()
+    cam = pkg.scenes.load_scene(sc, scene_id, w, h, tex_size=64)
+    prm = pkg.make_params(spp, "mis", "sobol")
+    films = {}
+    for name, step in (("one", spp), ("by64", 64), ("by16", 16)):
+        a = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        for s0 in range(0, spp, step):
+            product.render_accum_device(sc, cam, prm, s0, s0 + step, a.data_ptr(), None)
+        torch.cuda.synchronize()
+        films[name] = a.cpu().numpy()
+    sharded = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    for k in range(3):
+        product.render_accum_device(sc, cam, pkg.make_params(spp, "mis", "sobol", shard_index=k, shard_count=3), 0, spp, sharded.data_ptr(), None)
+    torch.cuda.synchronize()
+    ref = films["one"]
+    assert ref.mean() > 0.01 * spp * 0.1
+    for name in ("by64", "by16"):
+        np.testing.assert_allclose(films[name], ref, rtol=2e-4, atol=1e-4 * spp * 0.01)
+    # (a third of the tiles per launch: the launcher may split sample ranges differently, so again only the summation order moves)
+    np.testing.assert_allclose(sharded.cpu().numpy(), ref, rtol=2e-4, atol=1e-4 * spp * 0.01)
+    if spp <= 1024:
+        so = oracle.new_scene()
+        cam_o = pkg.scenes.load_scene(so, scene_id, w, h, tex_size=64)
+        oracle.set_faithful(so, False)
+        img_o = oracle.render(so, cam_o, prm)
+        img_g = product.render(sc, cam, prm)
+        assert linear_rmse_u8(product.quantize_u8(img_g), oracle.quantize_u8(img_o)) <= 0.01
+
+
 def test_cpp_host_cli_matches_python_binding(product, pkg, tmp_path):
     """The C++ mirror of the reference's renderer API (toy-cpu-pathtracing_amd/host: Scene::load_obj, load_scene_3,
     RendererImage::render/save, main.rs flags) must produce the picture the ctypes path produces: same library, same
