@@ -366,8 +366,10 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     // split the sample range only when there are too few items to fill the chip (small images / many shards): about 8 work
     // items per resident wave, but no chunk under 16 samples (every work item rebuilds its Sobol prefix tables; measured
     // with tools/chunk_sweep.sh: one shard of 4 / 8 at 1080p is 2.2 % / 0.9 % faster with 16-sample than with 8-sample chunks)
+    // (while some resident waves would have no item at all, chunks may go down to 8 samples: a 256x256 frame has 1 024 tiles)
     uint32_t chunks = 1;
-    while (n_items * chunks < (uint32_t)waves * 8 && chunks * 2 <= n_samples && (n_samples / (chunks * 2)) >= 16) chunks *= 2;
+    while (n_items * chunks < (uint32_t)waves * 8 && chunks * 2 <= n_samples &&
+           (n_samples / (chunks * 2)) >= (n_items * chunks >= (uint32_t)waves ? 16u : 8u)) chunks *= 2;
     if (const char* e = getenv("MI355PT_CHUNKS")) { uint32_t c = (uint32_t)atoi(e); if (c >= 1 && c <= n_samples) chunks = c; }   // tuning experiment
     dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
     dp.n_work = n_items * chunks;
