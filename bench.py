@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1]): scene3 (textured + normal-mapped Lambert he
 stand-in assets), MIS + ZSobol, 1920x1080, target 1024 spp.  One *step* = one pass of the hot path over one batch =
 what one `RendererImage::render()` call of the reference does: the whole 1920x1080 frame at all 1024 sample indices of
 the job, into a zeroed film (132.7 M pixel-samples x 16; `--spp-per-step S` < spp splits the job into consecutive
-ranges of S sample indices per step instead, e.g. progressive refinement; jobs above 1024 spp always use ranges of 1024).
+ranges of S sample indices per step instead, e.g. progressive refinement; jobs above 4096 spp use ranges of 4096).
 Inputs (BVH, triangles, materials, LUTs, tables, textures) are resident in HBM before the timed region; the film
 accumulators stay in HBM.
 
@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=0, help="sample indices per step; 0 = the whole job, at most 1024")
+    ap.add_argument("--spp-per-step", type=int, default=0, help="sample indices per step; 0 = the whole job, at most 4096")
     ap.add_argument("--scene", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -86,7 +86,7 @@ def main():
     cam = pkg.scenes.load_scene(scene, args.scene, args.width, args.height)     # BVH build + upload to this rank's GPU
     W, H = args.width, args.height
     spp_job = args.spp
-    sps = args.spp_per_step if args.spp_per_step > 0 else min(spp_job, 1024)
+    sps = args.spp_per_step if args.spp_per_step > 0 else min(spp_job, 4096)
     n_slices = max(spp_job // sps, 1)
     frame_per_step = n_slices == 1      # every step is a complete frame: zeroed film in, reduced film out
 

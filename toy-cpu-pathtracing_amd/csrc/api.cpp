@@ -373,6 +373,14 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     if (const char* e = getenv("MI355PT_CHUNKS")) { uint32_t c = (uint32_t)atoi(e); if (c >= 1 && c <= n_samples) chunks = c; }   // tuning experiment
     dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
     dp.n_work = n_items * chunks;
+    // single-pixel items whose sample ranges are aligned blocks of 4^m indices: the sample digits above m are item-uniform as well
+    dp.sample_prefix_digits = 0;
+    if (dp.sampler == MI355PT_SAMPLER_SOBOL && block_log2 == 0 && (dp.log2_spp & 1u) == 0u && n_samples % chunks == 0) {
+        const uint32_t cs = dp.chunk_size;
+        uint32_t m = 0;
+        while ((1u << (2u * (m + 1u))) <= cs) ++m;
+        if ((1u << (2u * m)) == cs && s_begin % cs == 0 && m >= 3 && m <= dp.log2_spp / 2u) dp.sample_prefix_digits = dp.log2_spp / 2u - m;
+    }
     LaunchCtx* lc; int slot;
     if ((rc = get_launch_ctx(s, p->seed, stream, &lc, &slot))) return rc;
     unsigned* d_counter = lc->d_counters + slot;
@@ -514,7 +522,7 @@ int mi355pt_probe_radiance(const mi355pt_scene* s, const mi355pt_camera* cam, co
     if (n == 0) return MI355PT_OK;
     DevCamera dc = make_camera(cam);
     DevParams dp = make_params(cam, p, 0, p->spp);
-    dp.chunks = 1; dp.chunk_size = 1; dp.block_log2 = 3; dp.n_work = (n + 63) / 64;
+    dp.chunks = 1; dp.chunk_size = 1; dp.block_log2 = 3; dp.sample_prefix_digits = 0; dp.n_work = (n + 63) / 64;
     LaunchCtx* lc; int slot;
     if ((rc = get_launch_ctx(s, p->seed, nullptr, &lc, &slot))) return rc;
     HIP_TRY(hipMemset(lc->d_counters + slot, 0, sizeof(unsigned)));

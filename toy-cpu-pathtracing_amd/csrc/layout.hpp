@@ -175,6 +175,8 @@ struct DevParams {
     uint32_t chunks, chunk_size;            // sample-range split per tile (1 = none)
     uint32_t block_log2;                    // a work item covers a 2^b x 2^b pixel block of its 8x8 tile (3: the whole tile); fewer pixels
                                             // per item leave fewer per-lane Sobol digits to hash (pt_kernels.hip)
+    uint32_t sample_prefix_digits;          // single-pixel items (b = 0) over aligned 4^m sample blocks: this many top base-4 digits of the
+                                            // sample index are item-uniform too and join the Sobol prefix tables
     uint32_t stats_mode;                    // instrumented variant only: 1 = reference traversal order (canonical counts), 2 = production traversal
     float xyz_to_rgb[9];                    // row-major sRGB matrix (gamut.rs:50-63)
 };

@@ -141,8 +141,7 @@ struct SamplerCtx {
 // sample index is a function of (tile, dimension) alone.  It is computed once per tile and dimension by one lane.
 // `block_log2`: the work item's pixels form an aligned 2^b x 2^b block, so they share every Morton digit above the lowest b.
 PT_DEV uint32_t sobol_hi_first(uint32_t log2_spp, uint32_t block_log2) { return (log2_spp + 1u) / 2u + block_log2; }
-PT_DEV uint64_t sobol_tile_hi_digits(uint32_t tile_morton_shifted, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits, uint32_t block_log2) {
-    const uint32_t first = sobol_hi_first(log2_spp, block_log2);
+PT_DEV uint64_t sobol_tile_hi_digits(uint32_t tile_morton_shifted, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits, uint32_t first) {
     uint64_t out = 0;
     const bool pow2 = (log2_spp & 1u) != 0;
     const uint64_t dmix = 0x55555555ull * (uint64_t)dimension;

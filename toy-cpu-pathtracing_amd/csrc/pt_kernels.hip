@@ -125,13 +125,15 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         const LaneJob job = lane_job<PROBE>(work, lane, cam, prm, probe_xys, n_probe);
         const LaneJob job0 = lane_job<PROBE>(work, 0u, cam, prm, probe_xys, n_probe);
         const uint32_t blk_log2 = PROBE ? 3u : prm.block_log2, blk_mask = (1u << blk_log2) - 1u;
-        if (!PROBE && prm.sampler == 1u && sobol_hi_first(prm.log2_spp, blk_log2) < prm.n_base4_digits) {
-            // block-uniform Sobol digit prefixes: lane d computes dimension d for this block (lane 0's pixel is the block origin)
-            sctx.hi_first = sobol_hi_first(prm.log2_spp, blk_log2);
+        const uint32_t s_prefix = PROBE ? 0u : prm.sample_prefix_digits;
+        if (!PROBE && prm.sampler == 1u && sobol_hi_first(prm.log2_spp, blk_log2) - s_prefix < prm.n_base4_digits) {
+            // block-uniform Sobol digit prefixes: lane d computes dimension d for this block (lane 0's pixel is the block origin).
+            // Single-pixel items over an aligned 4^m block of sample indices: the sample digits above m are part of the prefix.
+            sctx.hi_first = sobol_hi_first(prm.log2_spp, blk_log2) - s_prefix;
             sctx.hi_shift = 2u * sctx.hi_first - (prm.log2_spp & 1u);
-            const uint32_t tile_m = encode_morton2_u32(job0.px, job0.py) << prm.log2_spp;
+            const uint32_t tile_m = (encode_morton2_u32(job0.px, job0.py) << prm.log2_spp) | (s_prefix ? job0.s_cur : 0u);
             for (uint32_t dmn = lane; dmn < (uint32_t)SOBOL_HI_DIMS; dmn += 64) {
-                uint32_t e = (uint32_t)(sobol_tile_hi_digits(tile_m, dmn, prm.log2_spp, prm.n_base4_digits, blk_log2) >> sctx.hi_shift);   // <= 26 bits: the Morton index is a u32 and hi_shift >= 6
+                uint32_t e = (uint32_t)(sobol_tile_hi_digits(tile_m, dmn, prm.log2_spp, prm.n_base4_digits, sctx.hi_first) >> sctx.hi_shift);   // <= 26 bits: the Morton index is a u32 and hi_shift >= 6
                 const uint64_t prefix = (uint64_t)tile_m >> sctx.hi_shift;                 // the digits above digit hi_first-1
                 e |= sobol_perm_index(prefix, dmn) << 27;
                 uint32_t e6 = 0;
