@@ -27,8 +27,11 @@ struct Box {
 };
 
 // SAH cost ratio and leaf size: defaults measured on MI355X; env overrides exist for sweeps only
-static float COST_TRAVERSE = 1.0f, COST_TRI = 2.0f;   // a watertight triangle test costs about two node steps on gfx950
-static int LEAF_MAX = 2;                             // leaf loops run to the longest leaf of the wave: 2 measured best (+3 %)
+// With per-lane triangle tests a watertight test cost about two node steps and 2-triangle leaves were best; since leaves only
+// queue (triangle, ray) pairs that the whole wave tests densely, a triangle is cheaper than a node step: tools/sah_sweep.sh on
+// scenes 3 / 17 / 0 puts the plateau at 0.6-1.0 with leaves of up to 4 (+1.2 % over 2.0 / 2).
+static float COST_TRAVERSE = 1.0f, COST_TRI = 0.8f;
+static int LEAF_MAX = 4;
 
 struct Builder {
     const std::vector<BuildTri>& tris;

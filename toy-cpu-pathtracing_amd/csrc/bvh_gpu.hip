@@ -2,7 +2,7 @@
 //
 // Replaces, for large scenes, the host sweep-SAH builder (bvh_builder.cpp), which itself stands where the reference
 // has Bvh::build (scene/src/bvh.rs:92-230, O(n^2) split evaluation per level).  Same output contract as build_bvh():
-// DevNode records holding BOTH child boxes, leaves of <= LEAF_MAX leaf-ordered triangles, depth <= MAX_BUILD_DEPTH
+// DevNode records holding BOTH child boxes, leaves of <= LEAF_MAX (4) leaf-ordered triangles, depth <= MAX_BUILD_DEPTH
 // so the per-lane LDS traversal stack (STACK_DEPTH) cannot overflow, and a deterministic result.
 //
 // One level of the tree per round of launches.  Every open node ("work range") owns a contiguous range of the
