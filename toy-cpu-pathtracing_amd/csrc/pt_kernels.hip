@@ -465,7 +465,7 @@ __global__ void combine_kernel(DevCamera cam, DevParams prm, const float* __rest
 // ---------------------------------------------------------------------------------------------
 // smallest compiled specialisation covering `feat`
 static uint32_t pick_features(uint32_t feat) {
-    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_CC, FEAT_ALL & ~FEAT_CC, FEAT_ALL};
+    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_METAL, FEAT_DIEL | FEAT_ROUGH, FEAT_CC, FEAT_CC | FEAT_TEX, FEAT_ALL & ~FEAT_CC, FEAT_ALL};
     for (uint32_t s : sets) if ((feat & ~s) == 0u) return s;
     return FEAT_ALL;
 }
@@ -480,12 +480,15 @@ hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& 
         case 0u: PT_LAUNCH(0u); break;
         case FEAT_TEX: PT_LAUNCH(FEAT_TEX); break;
         case FEAT_DIEL: PT_LAUNCH(FEAT_DIEL); break;
+        case FEAT_METAL: PT_LAUNCH(FEAT_METAL); break;
+        case FEAT_DIEL | FEAT_ROUGH: PT_LAUNCH(FEAT_DIEL | FEAT_ROUGH); break;
         case FEAT_CC: PT_LAUNCH(FEAT_CC); break;
+        case FEAT_CC | FEAT_TEX: PT_LAUNCH(FEAT_CC | FEAT_TEX); break;
         case FEAT_ALL & ~FEAT_CC: PT_LAUNCH(FEAT_ALL & ~FEAT_CC); break;
         default: PT_LAUNCH(FEAT_ALL); break;
     }
     if (prm.chunks > 1) {
-        const uint32_t n_tiles = prm.n_work / prm.chunks;
+        const uint32_t n_tiles = (prm.n_work / prm.chunks) >> (6u - 2u * prm.block_log2);   // n_work = tiles * blocks per tile * chunks
         hipLaunchKernelGGL(combine_kernel, dim3(n_tiles), dim3(64), 0, stream, cam, prm, (const float*)d_partial, d_accum, n_tiles);
     }
     return hipGetLastError();
@@ -548,7 +551,10 @@ int query_resident_waves(uint32_t feat) {
         case 0u: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, 0u>, 64, 0); break;
         case FEAT_TEX: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_TEX>, 64, 0); break;
         case FEAT_DIEL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_DIEL>, 64, 0); break;
+        case FEAT_METAL: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_METAL>, 64, 0); break;
+        case FEAT_DIEL | FEAT_ROUGH: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_DIEL | FEAT_ROUGH>, 64, 0); break;
         case FEAT_CC: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_CC>, 64, 0); break;
+        case FEAT_CC | FEAT_TEX: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_CC | FEAT_TEX>, 64, 0); break;
         case FEAT_ALL & ~FEAT_CC: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_ALL & ~FEAT_CC>, 64, 0); break;
         default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, FEAT_ALL>, 64, 0); break;
     }
