@@ -233,7 +233,7 @@ def main():
 
 
 def scene_info(prod, scene):
-    return "flat single-level BVH2 (sweep SAH), 64 B nodes with both child boxes, <=2 tris/leaf; " + prod.scene_info(scene)
+    return "flat single-level BVH2 (SAH; builder and timings follow), 64 B nodes with both child boxes, <=4 tris/leaf; " + prod.scene_info(scene)
 
 
 if __name__ == "__main__":
