@@ -55,8 +55,13 @@ struct Builder {
         if (n == 1) return make_leaf_here();
         float leaf_cost = COST_TRI * (float)n;
         float best_cost = FLT_MAX; int best_axis = -1; uint32_t best_split = 0;
-        // keep depth + ceil(log2 n) <= MAX_BUILD_DEPTH so the LDS traversal stack (STACK_DEPTH) cannot overflow
-        bool force_median = n > (1u << std::min(31, std::max(0, MAX_BUILD_DEPTH - depth - 1)));
+        // Depth bound (the LDS traversal stack holds STACK_DEPTH entries): a node with `levels_left` split levels below it can
+        // always be finished by object-median splits if n <= MAX_LEAF_TRIS << levels_left; SAH may split freely only while both
+        // children are sure to stay inside that bound, otherwise the split is the median.
+        const int levels_left = MAX_BUILD_DEPTH - depth;
+        const bool must_leaf = levels_left <= 0;
+        const bool force_median = !must_leaf && (uint64_t)n > ((uint64_t)MAX_LEAF_TRIS << std::min(40, levels_left - 1));
+        if (must_leaf) return make_leaf_here();   // n <= MAX_LEAF_TRIS by the bound above (build_bvh checks the root)
         if (!force_median) {
             float inv_area = 1.0f / std::max(box.area(), 1e-30f);
             for (int axis = 0; axis < 3; ++axis) {

@@ -78,6 +78,14 @@ __device__ __forceinline__ void box_merge(float* b, const float* o) {
     for (int a = 0; a < 3; ++a) { b[a] = fminf(b[a], o[a]); b[3 + a] = fmaxf(b[3 + a], o[3 + a]); }
 }
 
+// Depth bound, the same rule as the host builder: a range with `levels_left` split levels below it can always be finished by
+// median splits if n <= MAX_LEAF_TRIS << levels_left; SAH may choose freely only while both children stay inside that bound.
+__device__ __forceinline__ bool depth_forces_median(uint32_t n, uint32_t depth) {
+    const int levels_left = MAX_BUILD_DEPTH - (int)depth;
+    if (levels_left <= 0) return false;                          // the range becomes a leaf
+    return (uint64_t)n > ((uint64_t)MAX_LEAF_TRIS << (levels_left - 1));
+}
+
 __device__ __forceinline__ uint32_t bin_of(const Work& wk, const BuildTri& t, uint32_t i, uint32_t axis) {
     if (wk.mode == MODE_RANK) return (uint32_t)(((uint64_t)(i - wk.begin) * NBINS) / (uint64_t)(wk.end - wk.begin));
     float x = (t.c[axis] - wk.cmin[axis]) * wk.scale[axis];
@@ -131,9 +139,7 @@ __device__ __forceinline__ void open_range(Work* w, uint32_t begin, uint32_t end
         ext_max = fmaxf(ext_max, e);
     }
     uint32_t n = end - begin;
-    int levels_left = MAX_BUILD_DEPTH - (int)child_depth - 1;
-    bool force_median = levels_left < 0 || (levels_left < 31 && n > (1u << levels_left));
-    bool rank = force_median || !(ext_max > 1e-20f);
+    bool rank = depth_forces_median(n, child_depth) || !(ext_max > 1e-20f);
     w->mode = rank ? MODE_RANK : MODE_SPATIAL; w->pad = 0;
 }
 __global__ void k_root(Work* work, const uint32_t* bounds6, uint32_t n) {
@@ -213,8 +219,8 @@ __global__ __launch_bounds__(BLOCK) void k_split(const Work* __restrict__ work, 
     if (w >= w_hi) return;
     const Work wk = work[w];
     const uint32_t n = wk.end - wk.begin;
-    const int levels_left = MAX_BUILD_DEPTH - (int)depth - 1;
-    const bool force_median = levels_left < 0 || (levels_left < 31 && n > (1u << levels_left));
+    const bool must_leaf = (int)depth >= MAX_BUILD_DEPTH;       // n <= MAX_LEAF_TRIS here, by the bound in depth_forces_median
+    const bool force_median = depth_forces_median(n, depth);
     float best_cost = FLT_MAX; int best = -1; uint32_t best_axis = 0;
     const uint32_t n_axes = wk.mode == MODE_RANK ? 1u : 3u;
     for (uint32_t axis = 0; axis < n_axes; ++axis) {
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(BLOCK) void k_split(const Work* __restrict__ work, 
     Decision d;
     memset(&d, 0, sizeof(d));
     const float leaf_cost = cfg.cost_tri * (float)n;
-    if (!force_median && n <= cfg.leaf_max && leaf_cost <= best_cost) {
+    if (must_leaf || (!force_median && n <= cfg.leaf_max && leaf_cost <= best_cost)) {
         d.kind = DEC_LEAF;
         dec[w] = d;
         alloc[w] = 0;
@@ -390,6 +396,7 @@ bool build_bvh_gpu(const std::vector<BuildTri>& tris, BvhOut* out, double* devic
     float cost_traverse, cost_tri; int leaf_max;
     bvh_build_config(&cost_traverse, &cost_tri, &leaf_max);
     if (n < 8) { *err = "GPU BVH build: fewer than 8 triangles (use the host builder)"; return false; }
+    if ((uint64_t)n > ((uint64_t)MAX_LEAF_TRIS << MAX_BUILD_DEPTH)) { *err = "GPU BVH build: too many triangles for the depth bound"; return false; }
     Config cfg{cost_traverse, cost_tri, (uint32_t)leaf_max};
 
     bool ok = true;

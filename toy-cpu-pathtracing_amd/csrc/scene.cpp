@@ -279,7 +279,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         }
     }
     if (btris.empty()) { *err = "scene has no triangles"; return MI355PT_E_INVALID; }
-    if (btris.size() >= (1u << 28)) { *err = "too many triangles"; return MI355PT_E_INVALID; }
+    if (btris.size() > ((size_t)MAX_LEAF_TRIS << MAX_BUILD_DEPTH)) { *err = "too many triangles"; return MI355PT_E_INVALID; }   // 16.7 M: depth bound of the traversal stack
 
     // BVH: host sweep SAH, or the GPU binned-SAH builder for large triangle counts
     BvhOut bvh;
