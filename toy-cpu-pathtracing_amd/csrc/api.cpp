@@ -334,11 +334,22 @@ int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam) {
     return rc ? fail(rc, err) : MI355PT_OK;
 }
 
+static constexpr uint32_t PT_MAX_LAUNCH_SAMPLES = 4096;
 int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end,
                                 float* d_accum, void* hip_stream, mi355pt_stats* stats) {
     int rc = check_args(s, cam, p);
     if (rc) return rc;
     if (!d_accum || s_end > p->spp || s_begin >= s_end) return fail(MI355PT_E_INVALID, "bad sample range or null accumulator");
+    if (p->sampler == MI355PT_SAMPLER_SOBOL && !stats && s_end - s_begin > PT_MAX_LAUNCH_SAMPLES) {
+        // long Sobol ranges go out as aligned blocks of 4096 sample indices: single-pixel work items over an aligned 4^6 block hash the
+        // fewest digits per draw (the digits above the block join the prefix tables), and no launch runs for minutes
+        for (uint32_t b = s_begin; b < s_end;) {
+            const uint32_t e = std::min(s_end, (b / PT_MAX_LAUNCH_SAMPLES + 1u) * PT_MAX_LAUNCH_SAMPLES);
+            if ((rc = mi355pt_render_accum_device(s, cam, p, b, e, d_accum, hip_stream, nullptr))) return rc;
+            b = e;
+        }
+        return MI355PT_OK;
+    }
     hipStream_t stream = (hipStream_t)hip_stream;
     DevCamera dc = make_camera(cam);
     DevParams dp = make_params(cam, p, s_begin, s_end);
