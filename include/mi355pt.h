@@ -79,7 +79,7 @@ typedef struct mi355pt_material_desc {
     /* FloatParameter::texture(FloatTexture::load(path, false)) for metallic / roughness (SimplePbr, clearcoat) and the metal's
      * roughness: texture ids from add_tex_rgb8 (a grey image replicated to RGB; the red channel is read with the same bilinear
      * rule, texture/sampler.rs:81-107), MI355PT_NONE = the constant above.  material/parameter.rs:58-83 */
-    uint32_t metallic_tex, roughness_tex;
+    uint32_t metallic_tex, roughness_tex;   /* roughness_tex also on glass / plastic (glass_material.rs:42,116, plastic_material.rs:43,104) */
     uint32_t clearcoat_thickness_tex;   /* clearcoat only (scene_18.rs:37-42) */
 } mi355pt_material_desc;
 

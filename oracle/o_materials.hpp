@@ -582,7 +582,8 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
         M4 tf_inv = inverse(tf);
         V3 wo_nm = transform_vector3(tf, wo);
         bool entering = dot(sp.normal, wo) > 0.0f;
-        DielectricBsdf bsdf(eta, entering, m.thin, m.roughness, m.roughness);
+        const float d_rough = scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv);   // FloatParameter::sample (glass_material.rs:116)
+        DielectricBsdf bsdf(eta, entering, m.thin, d_rough, d_rough);
         BsdfSample bs;
         if (!bsdf.sample(wo_nm, uv, uc, wl, &bs)) return ms;
         if (m.type == MAT_PLASTIC && dot(bs.wi, wo_nm) < 0.0f) {
@@ -630,7 +631,8 @@ inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
         bool entering = dot(sp.normal, wo) > 0.0f;
-        DielectricBsdf bsdf(eta, entering, m.thin, m.roughness, m.roughness);
+        const float d_rough = scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv);   // FloatParameter::sample (glass_material.rs:116)
+        DielectricBsdf bsdf(eta, entering, m.thin, d_rough, d_rough);
         SS f = bsdf.evaluate(wo_nm, wi_nm);
         if (m.type == MAT_PLASTIC && dot(wi_nm, wo_nm) < 0.0f) f = f * scene.sample_spectrum_param(m.color, sp.uv, wl, ctr);
         return f;
@@ -668,7 +670,8 @@ inline float MaterialEval::pdf(const Material& m, const Wavelengths& wl, V3 wo, 
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
         bool entering = dot(sp.normal, wo) > 0.0f;
-        DielectricBsdf bsdf(eta, entering, m.thin, m.roughness, m.roughness);
+        const float d_rough = scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv);   // FloatParameter::sample (glass_material.rs:116)
+        DielectricBsdf bsdf(eta, entering, m.thin, d_rough, d_rough);
         return bsdf.pdf(wo_nm, wi_nm);
     }
     return 0.0f;

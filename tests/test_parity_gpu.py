@@ -155,7 +155,8 @@ def test_gpu_pt_nee_mis_consistency_metal(product, pkg):
 @pytest.mark.parametrize("scene_id,strategy", [(8, "mis"), (10, "mis"), (0, "nee"), (17, "nee"), (17, "mis"), (11, "mis"), (11, "nee"),
                                                (6, "mis"), (7, "mis"), (7, "nee"), (20, "mis"), (20, "pt"),
                                                (1, "nee"), (2, "mis"), (21, "mis"), (21, "nee"), (19, "mis"), (19, "pt"), (19, "nee"), (22, "mis"), (22, "nee"),
-                                               (4, "mis"), (5, "nee"), (9, "mis"), (12, "mis"), (13, "mis"), (14, "nee"), (15, "mis"), (16, "mis"), (18, "nee")])
+                                               (4, "mis"), (5, "nee"), (9, "mis"), (12, "mis"), (13, "mis"), (14, "nee"), (15, "mis"), (16, "mis"), (18, "nee"),
+                                               (27, "mis"), (27, "nee"), (27, "pt")])
 def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     """Glass (scene 8: dispersive, wavelength termination), thin plastic (scene 10), plain Lambert (scene 0), rough clearcoat
     over rough metal (scene 17), rough SF11 glass (scene 11: microfacet reflection/transmission + light connection), smooth
@@ -164,7 +165,8 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     together (scene 21, not a reference scene), environment light over SimplePbr / clearcoat / plastic heroes (scene 19), SimplePbr with FloatTexture metallic / roughness maps,
     textured base colour and a normal map (scenes 15 and 22), and the remaining Cornell scenes of the reference: 4 / 5 (other
     texture set, normal map only), 9 / 13 (plastic without thin film, linear-sRGB colour), 12 / 14 (four rough BK7 glass / coloured
-    rough plastic heroes), 16 / 18 (near-smooth coat, FloatTexture coat thickness)."""
+    rough plastic heroes), 16 / 18 (near-smooth coat, FloatTexture coat thickness); glass and plastic with a FloatTexture roughness
+    that switches between the specular and the microfacet branch across the surface (scene 27, not a reference scene)."""
     pair = {}
     for name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()
@@ -201,7 +203,7 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     qc = oracle.quantize_u8(oracle.render(pair["cpu"][0], pair["cpu"][1], prm8))
     # 8-spp frames: a refracted path that flips at a geometric edge moves its pixel by a lot (solid dielectric heroes), and a NaN
     # sample blacks out its pixel (`as u8`, scene 11)
-    tol = {11: 0.03, 9: 0.02, 12: 0.02, 13: 0.02, 14: 0.02}.get(scene_id, 0.01)
+    tol = {11: 0.03, 9: 0.02, 12: 0.02, 13: 0.02, 14: 0.02, 27: 0.02}.get(scene_id, 0.01)
     assert linear_rmse_u8(qg, qc) <= tol
 
 
@@ -371,6 +373,23 @@ def test_launch_shape_does_not_change_the_frame(product, oracle, pkg, scene_id, 
         img_o = oracle.render(so, cam_o, prm)
         img_g = product.render(sc, cam, prm)
         assert linear_rmse_u8(product.quantize_u8(img_g), oracle.quantize_u8(img_o)) <= 0.01
+
+
+def test_dielectric_roughness_map_is_used(product, oracle, pkg):
+    """Scene 27 (glass + plastic with a FloatTexture roughness) against scene 28 (same heroes, constant roughness 0): the map must
+    change the frame on both sides, and by the same amount."""
+    frames = {}
+    for name, be in (("gpu", product), ("cpu", oracle)):
+        for sid in (27, 28):
+            sc = be.new_scene()
+            cam = pkg.scenes.load_scene(sc, sid, 128, 96, tex_size=256)
+            if name == "cpu":
+                oracle.set_faithful(sc, False)
+            frames[name, sid] = be.quantize_u8(be.render(sc, cam, pkg.make_params(64, "mis", "sobol")))
+    d_gpu = linear_rmse_u8(frames["gpu", 27], frames["gpu", 28])
+    d_cpu = linear_rmse_u8(frames["cpu", 27], frames["cpu", 28])
+    assert d_gpu > 0.01 and abs(d_gpu - d_cpu) <= 0.2 * d_cpu, (d_gpu, d_cpu)
+    assert linear_rmse_u8(frames["gpu", 27], frames["cpu", 27]) <= 0.02
 
 
 def test_cpp_host_cli_matches_python_binding(product, pkg, tmp_path):

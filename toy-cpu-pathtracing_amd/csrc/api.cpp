@@ -239,6 +239,10 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
         if (d->clearcoat_thickness_tex >= im.textures.size()) return fail(MI355PT_E_INVALID, "bad clearcoat thickness texture id");
         m.cc_thickness_tex = d->clearcoat_thickness_tex;
     }
+    if (d->type == MI355PT_MAT_GLASS || d->type == MI355PT_MAT_PLASTIC) {   // roughness: FloatParameter (glass_material.rs:42, plastic_material.rs:43)
+        if (d->roughness_tex != MI355PT_NONE && d->roughness_tex >= im.textures.size()) return fail(MI355PT_E_INVALID, "bad roughness texture id");
+        m.roughness_tex = d->roughness_tex;
+    }
     if (d->type == MI355PT_MAT_SIMPLE_PBR || d->type == MI355PT_MAT_CLEARCOAT || d->type == MI355PT_MAT_METAL) {
         if ((d->metallic_tex != MI355PT_NONE && d->metallic_tex >= im.textures.size()) || (d->roughness_tex != MI355PT_NONE && d->roughness_tex >= im.textures.size()))
             return fail(MI355PT_E_INVALID, "bad metallic/roughness texture id");

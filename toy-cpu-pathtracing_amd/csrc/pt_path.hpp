@@ -350,7 +350,9 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
             const bool is_diel = (FEAT & FEAT_DIEL) && (mtype == MT_GLASS || mtype == MT_PLASTIC);
             float uc = 0.0f;
             f2 uv = f2{0.0f, 0.0f};
-            const bool rough_diel = (FEAT & FEAT_ROUGH) && is_diel && mat->roughness >= 1e-3f;    // !effectively_smooth (dielectric.rs:25-27)
+            float d_alpha = mat->roughness;                                   // FloatParameter::sample(uv) (glass_material.rs:116, plastic_material.rs:104)
+            if ((FEAT & FEAT_TEX) && (FEAT & FEAT_ROUGH) && is_diel && mat->roughness_tex != 0xffffffffu) { float t3[3]; bilinear_rgb(sc, mat->roughness_tex, sf.uv, t3); d_alpha = t3[0]; }
+            const bool rough_diel = (FEAT & FEAT_ROUGH) && is_diel && d_alpha >= 1e-3f;            // !effectively_smooth (dielectric.rs:25-27)
             if (is_diel) {
                 uc = get_1d(smp, sctx);
                 // Plastic indexes a *textured* colour with the random uv (plastic_material.rs:123-126, Q15)
@@ -417,7 +419,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 if (rough_diel) {
                     // DielectricBsdf::sample_microfacet (dielectric.rs:217-365), alpha = roughness (glass_material.rs:120-126)
                     nee_kind = 3; d_thin = thin; d_plastic = mtype == MT_PLASTIC;
-                    const float alpha = mat->roughness;
+                    const float alpha = d_alpha;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d_er[i] = (thin || entering) ? eta[i] : sdiv(1.0f, eta[i]);
                     if (wo_nm.z != 0.0f) {
@@ -768,7 +770,7 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
                     float gwi = dot(ng_t, wi_t);
                     if ((FEAT & FEAT_ROUGH) && nee_kind == 3u) {                 // DielectricBsdf::{evaluate_microfacet,pdf_microfacet} (:468-645)
-                        const float alpha = mat->roughness;
+                        const float alpha = d_alpha;
                         const float es = d_er[0];
                         float co = wo_nm.z, ci = wi_nm.z;
                         bool refl = ci * co > 0.0f;
@@ -913,6 +915,7 @@ struct ShadeCtx {
     Surface sf; const DevMaterial* mat; uint32_t mtype;
     Frame fr, nf; f3 wo, wo_nm, ng_t; float geo_wo, uc; f2 uv;
     bool is_diel, rough_diel, cont;
+    float d_alpha;                 // dielectric roughness at the shading point (constant or FloatTexture)
     // clearcoat inputs / result of the cooperative estimate
     bool need_cc; float cc_alpha_c, cc_r0c, cc_thick, cc_metallic, cc_rough_b, cc_fc; uint64_t mc_key;
 };
@@ -1049,7 +1052,9 @@ PT_DEV bool shade_vertex_a(Path& P, const DevScene& sc, const DevParams& prm, co
             const bool is_diel = (FEAT & FEAT_DIEL) && (mtype == MT_GLASS || mtype == MT_PLASTIC);
             float uc = 0.0f;
             f2 uv = f2{0.0f, 0.0f};
-            const bool rough_diel = (FEAT & FEAT_ROUGH) && is_diel && mat->roughness >= 1e-3f;    // !effectively_smooth (dielectric.rs:25-27)
+            float d_alpha = mat->roughness;                                    // FloatParameter::sample(uv) (glass_material.rs:116, plastic_material.rs:104)
+            if ((FEAT & FEAT_TEX) && (FEAT & FEAT_ROUGH) && is_diel && mat->roughness_tex != 0xffffffffu) { float t3[3]; bilinear_rgb(sc, mat->roughness_tex, sf.uv, t3); d_alpha = t3[0]; }
+            const bool rough_diel = (FEAT & FEAT_ROUGH) && is_diel && d_alpha >= 1e-3f;            // !effectively_smooth (dielectric.rs:25-27)
             if (is_diel) {
                 uc = get_1d(smp, sctx);
                 // Plastic indexes a *textured* colour with the random uv (plastic_material.rs:123-126, Q15)
@@ -1074,7 +1079,7 @@ PT_DEV bool shade_vertex_a(Path& P, const DevScene& sc, const DevParams& prm, co
             f3 wo_nm = to_local(nf, wo);
             // ---- hand-over to the second half ----
             C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; C.nf = nf; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
-            C.geo_wo = dot(ng_t, wo); C.uc = uc; C.uv = uv; C.is_diel = is_diel; C.rough_diel = rough_diel; C.cont = true;
+            C.geo_wo = dot(ng_t, wo); C.uc = uc; C.uv = uv; C.is_diel = is_diel; C.rough_diel = rough_diel; C.d_alpha = d_alpha; C.cont = true;
             if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) {
                 // SimpleClearcoatPbrMaterial: FloatParameter values at the shading point + the inputs of the coat's directional albedo
                 float metallic = mat->metallic; float thick = mat->cc_thickness;
@@ -1156,7 +1161,7 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                 if (rough_diel) {
                     // DielectricBsdf::sample_microfacet (dielectric.rs:217-365), alpha = roughness (glass_material.rs:120-126)
                     nee_kind = 3; d_thin = thin; d_plastic = mtype == MT_PLASTIC;
-                    const float alpha = mat->roughness;
+                    const float alpha = C.d_alpha;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d_er[i] = (thin || entering) ? eta[i] : sdiv(1.0f, eta[i]);
                     if (wo_nm.z != 0.0f) {
@@ -1498,7 +1503,7 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                     float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
                     float gwi = dot(ng_t, wi_t);
                     if ((FEAT & FEAT_ROUGH) && nee_kind == 3u) {                 // DielectricBsdf::{evaluate_microfacet,pdf_microfacet} (:468-645)
-                        const float alpha = mat->roughness;
+                        const float alpha = C.d_alpha;
                         const float es = d_er[0];
                         float co = wo_nm.z, ci = wi_nm.z;
                         bool refl = ci * co > 0.0f;

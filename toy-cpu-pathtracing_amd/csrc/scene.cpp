@@ -410,7 +410,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     if (env.present) features |= FEAT_ENV;
     for (const HostInstance& inst : instances) {
         const DevMaterial& m = materials[inst.mat];
-        if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | (m.roughness >= 1e-3f ? FEAT_ROUGH : 0u);
+        if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | ((m.roughness >= 1e-3f || m.roughness_tex != 0xffffffffu) ? FEAT_ROUGH : 0u);
         if (m.type == MT_CLEARCOAT) features |= FEAT_CC;
         if (m.type == MT_METAL) features |= FEAT_METAL;
         if (m.normal_tex != 0xffffffffu || m.color.kind == SPK_TEXTURE || m.cc_tint.kind == SPK_TEXTURE || m.metallic_tex != 0xffffffffu ||

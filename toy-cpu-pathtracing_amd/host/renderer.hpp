@@ -334,12 +334,12 @@ enum class GlassType { Bk7, Sf11 };
 struct GlassMaterial {
     static Material create(GlassType t, NormalParameter n, bool thin, FloatParameter rough) {
         Material m; m.type = MI355PT_MAT_GLASS; m.eta = t == GlassType::Sf11 ? presets::glass_sf11_eta() : presets::glass_bk7_eta();
-        m.color = SpectrumParameter::constant(ConstantSpectrum::create(1.0f)); m.normal = std::move(n); m.thin = thin; m.roughness = rough.v; return m;
+        m.color = SpectrumParameter::constant(ConstantSpectrum::create(1.0f)); m.normal = std::move(n); m.thin = thin; m.roughness = rough.v; m.roughness_tex = rough.tex; return m;
     }
 };
 struct PlasticMaterial {
     static Material create(float eta, SpectrumParameter color, NormalParameter n, bool thin, FloatParameter rough) {
-        Material m; m.type = MI355PT_MAT_PLASTIC; m.eta = ConstantSpectrum::create(eta); m.color = std::move(color); m.normal = std::move(n); m.thin = thin; m.roughness = rough.v; return m;
+        Material m; m.type = MI355PT_MAT_PLASTIC; m.eta = ConstantSpectrum::create(eta); m.color = std::move(color); m.normal = std::move(n); m.thin = thin; m.roughness = rough.v; m.roughness_tex = rough.tex; return m;
     }
 };
 enum class MetalType { Gold, Silver, Copper, Aluminum, Brass };                       // metal_material.rs:16-29

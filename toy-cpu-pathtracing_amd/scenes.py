@@ -236,6 +236,23 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
         _room(scene, p)
         cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    elif scene_id in (27, 28):   # not a reference scene: GlassMaterial / PlasticMaterial with FloatParameter::Texture roughness (28: the
+        # same heroes with the constant roughness 0, to show that the map is what makes the difference)
+        # (glass_material.rs:42,116, plastic_material.rs:43,104): BK7 glass and a coloured plastic hero whose roughness comes from a
+        # grey map that covers 0 (effectively smooth: the specular branch) to 0.5 (microfacet branch) across the surface
+        g = scene.add_mesh(_asset("bunny"))
+        albedo, _ = _asset(f"tex{tex_size}")
+        grey = lambda a: np.ascontiguousarray(np.repeat(a[..., None], 3, -1))
+        rmap = np.where(albedo[..., 1] < 96, 0, albedo[..., 1] // 2).astype(np.uint8)
+        t_rgh = scene.add_tex_rgb8(grey(rmap))
+        bk7 = Spectrum.lut(scene.add_lut470(p["glass_bk7_eta"]))
+        for pos, (mt, eta, col) in zip([(-0.7, 0.0, -0.5), (0.8, 0.0, -0.3)],
+                                       [(MAT_GLASS, bk7, Spectrum.constant(1.0)), (MAT_PLASTIC, Spectrum.constant(1.5), Spectrum.rgb_albedo_srgb(0.5, 0.8, 1.0))]):
+            d = MaterialDesc(); d.type = mt; d.eta = eta; d.color = col; d.normal_tex = NONE; d.thin = 0; d.roughness = 0.0; d.roughness_tex = t_rgh if scene_id == 27 else NONE
+            m = np.diag(np.array([0.9, 0.9, 0.9, 1.0], dtype=np.float32)); m[:3, 3] = np.array(pos, dtype=np.float32)
+            scene.add_instance(g, scene.add_material(d), m)
+        _room(scene, p)
+        cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
     elif scene_id == 26:   # not a reference scene: no light at all (every strategy must return a black frame)
         scene.add_instance(scene.add_mesh(_asset("bunny")), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
         _room(scene, p, with_light=False)
