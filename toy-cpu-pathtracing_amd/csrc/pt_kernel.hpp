@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
 
 // ---- launch of the production variants of one MODE: smallest compiled feature set covering `feat` ----
 inline uint32_t pick_features(uint32_t feat) {
-    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_METAL, FEAT_DIEL | FEAT_ROUGH, FEAT_CC, FEAT_CC | FEAT_TEX, FEAT_ALL & ~FEAT_CC, FEAT_ALL};
+    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_METAL, FEAT_DIEL | FEAT_ROUGH, FEAT_DELTA | FEAT_MLIGHT, FEAT_CC, FEAT_CC | FEAT_TEX, FEAT_ALL & ~FEAT_CC, FEAT_ALL};
     for (uint32_t s : sets) if ((feat & ~s) == 0u) return s;
     return FEAT_ALL;
 }
@@ -262,7 +262,7 @@ struct PtLaunchArgs {
     int grid; hipStream_t stream;
 };
 #define PT_FOR_EACH_FEATURE_SET(X) \
-    X(0u) X(FEAT_TEX) X(FEAT_DIEL) X(FEAT_METAL) X(FEAT_DIEL | FEAT_ROUGH) X(FEAT_CC) X(FEAT_CC | FEAT_TEX) X(FEAT_ALL & ~FEAT_CC) X(FEAT_ALL)
+    X(0u) X(FEAT_TEX) X(FEAT_DIEL) X(FEAT_METAL) X(FEAT_DIEL | FEAT_ROUGH) X(FEAT_DELTA | FEAT_MLIGHT) X(FEAT_CC) X(FEAT_CC | FEAT_TEX) X(FEAT_ALL & ~FEAT_CC) X(FEAT_ALL)
 template <uint32_t MODE>
 void launch_pt_mode(const PtLaunchArgs& a, uint32_t feat) {
     PathOut po{nullptr, nullptr, nullptr};
