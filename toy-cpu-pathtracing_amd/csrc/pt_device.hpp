@@ -82,7 +82,10 @@ PT_DEV uint32_t perm_packed(uint32_t p) {
 // (tile-uniform part, see sobol_tile_hi_digits); 0 / n_base4_digits computes everything here.
 // `perm_lds`: the 24 packed permutations as a byte table in LDS (the render kernel is VALU-issue bound; a ds_read_u8 replaces
 // the ~8 VALU instructions of perm_packed); nullptr: arithmetic selection
-PT_DEV uint32_t perm_lookup(const uint8_t* perm_lds, uint32_t p) { return perm_lds ? (uint32_t)perm_lds[p] : perm_packed(p); }
+// (the table is indexed by permutation * 4 + digit and holds the permuted digit: one v_lshl_add + ds_read_u8 per digit)
+PT_DEV uint32_t perm_digit(const uint8_t* perm_lds, uint32_t p, uint32_t digit) {
+    return perm_lds ? (uint32_t)perm_lds[p * 4u + digit] : ((perm_packed(p) >> (2u * digit)) & 3u);
+}
 PT_DEV uint64_t sobol_sample_index(uint32_t morton, uint32_t dimension, uint32_t log2_spp, uint32_t n_base4_digits, uint64_t hi_digits = 0ull,
                                    uint32_t hi_first = 0xffffu, const uint8_t* perm_lds = nullptr) {   // :101-156
     uint64_t sample_index = hi_digits;
@@ -97,7 +100,7 @@ PT_DEV uint64_t sobol_sample_index(uint32_t morton, uint32_t dimension, uint32_t
         // (mix >> 24) % 24 on a 40-bit value with 32-bit ops: 2^32 mod 24 == 16
         uint64_t mx = mix_bits(higher ^ dmix) >> 24;
         uint32_t p = (((uint32_t)(mx >> 32) * 16u) + ((uint32_t)mx % 24u)) % 24u;
-        digit = (perm_lookup(perm_lds, p) >> (2u * digit)) & 3u;
+        digit = perm_digit(perm_lds, p, digit);
         sample_index |= (uint64_t)digit << shift;
     }
     if (pow2) {
@@ -138,7 +141,7 @@ struct SamplerCtx {
     uint32_t hi_first;            // first digit index covered by hi_lds
     uint32_t hi_shift;            // bit position of that digit
     const uint32_t* p6_lds;       // per dimension: the permutation indices of digit hi_first-2 for the four values of digit hi_first-1
-    const uint8_t* perm_lds;      // the 24 packed digit permutations (perm_packed) as bytes, or nullptr
+    const uint8_t* perm_lds;      // the 24 digit permutations as a [permutation][digit] byte table (96 B), or nullptr
 };
 // The pixels of an aligned 8x8 tile share every Morton digit above the lowest three (2^b x 2^b block: the lowest b), and a digit's permutation
 // only depends on the digits above it and on the dimension (:134-145): for those digits the permuted prefix of the
@@ -178,8 +181,8 @@ PT_DEV uint64_t sampler_index(const Sampler& s, const SamplerCtx& c) {
         const uint32_t e = c.hi_lds[s.dimension], e6 = c.p6_lds[s.dimension];
         const uint32_t sh7 = c.hi_shift - 2u, sh6 = c.hi_shift - 4u;
         const uint32_t d7 = (s.morton >> sh7) & 3u, d6 = (s.morton >> sh6) & 3u;
-        const uint32_t q7 = (perm_lookup(c.perm_lds, e >> 27) >> (2u * d7)) & 3u;
-        const uint32_t q6 = (perm_lookup(c.perm_lds, (e6 >> (5u * d7)) & 31u) >> (2u * d6)) & 3u;
+        const uint32_t q7 = perm_digit(c.perm_lds, e >> 27, d7);
+        const uint32_t q6 = perm_digit(c.perm_lds, (e6 >> (5u * d7)) & 31u, d6);
         uint64_t hi = ((uint64_t)(e & 0x07ffffffu) << c.hi_shift) | ((uint64_t)q7 << sh7) | ((uint64_t)q6 << sh6);
         return sobol_sample_index(s.morton, s.dimension, c.log2_spp, c.n_base4_digits, hi, c.hi_first - 2u, c.perm_lds);
     }

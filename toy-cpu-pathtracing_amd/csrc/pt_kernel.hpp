@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
     __shared__ uint32_t s_p6[SOBOL_HI_DIMS];
     __shared__ unsigned s_work;
-    __shared__ uint8_t s_perm[24];
+    __shared__ uint8_t s_perm[96];
 #if PT_ANY_DEFERRED
     __shared__ uint32_t s_ring[ANY_RING];
     __shared__ uint32_t s_occl[2];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     const uint32_t lane = threadIdx.x;
     uint32_t* stack = s_stack + lane;
     // murmur(dimension, seed) comes straight from its 1 KB global table (L1-resident): the LDS it used holds the tile's film
-    if (lane < 24u) s_perm[lane] = (uint8_t)perm_packed(lane);
+    for (uint32_t k = lane; k < 96u; k += 64u) s_perm[k] = (uint8_t)((perm_packed(k >> 2) >> (2u * (k & 3u))) & 3u);
     __syncthreads();
     SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, dim_hash_tab, nullptr, 0u, 0u, nullptr, s_perm};
     StatCounters st{};
