@@ -374,8 +374,13 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
         while (block_log2 > 0 && ((uint64_t)n_samples << (2u * (block_log2 - 1u))) >= PT_MIN_ITEM_SAMPLES) --block_log2;
     }
     if (const char* e = getenv("MI355PT_BLOCK")) { int b = atoi(e); if (b >= 0 && b <= 3) block_log2 = (uint32_t)b; }   // tuning experiment
-    // the block-uniform digits are packed into 27 bits of a u32 Morton index: their first bit must be >= 6
-    while (block_log2 < 3 && 2u * ((dp.log2_spp + 1u) / 2u + block_log2) - (dp.log2_spp & 1u) < 6u) ++block_log2;
+    // the permuted block-uniform digits (everything above bit hi_shift of the 2 n - odd bit sample index) are packed into 27 bits
+    // of a table word: large frames (>= 16384 pixels wide) need a larger block
+    {
+        const uint32_t odd = dp.log2_spp & 1u, index_bits = 2u * dp.n_base4_digits - odd;
+        auto hi_shift = [&](uint32_t b) { return 2u * ((dp.log2_spp + 1u) / 2u + b) - odd; };
+        while (block_log2 < 3 && (hi_shift(block_log2) < 6u || index_bits > hi_shift(block_log2) + 27u)) ++block_log2;
+    }
     dp.block_log2 = block_log2;
     const uint32_t n_items = n_tiles * (64u >> (2u * block_log2));
     // split the sample range only when there are too few items to fill the chip (small images / many shards): about 8 work
@@ -394,7 +399,8 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
         const uint32_t cs = dp.chunk_size;
         uint32_t m = 0;
         while ((1u << (2u * (m + 1u))) <= cs) ++m;
-        if ((1u << (2u * m)) == cs && s_begin % cs == 0 && m >= 3 && m <= dp.log2_spp / 2u) dp.sample_prefix_digits = dp.log2_spp / 2u - m;
+        if ((1u << (2u * m)) == cs && s_begin % cs == 0 && m >= 3 && m <= dp.log2_spp / 2u &&
+            2u * dp.n_base4_digits <= 2u * m + 27u) dp.sample_prefix_digits = dp.log2_spp / 2u - m;   // prefix above bit 2m must fit 27 bits
     }
     LaunchCtx* lc; int slot;
     if ((rc = get_launch_ctx(s, p->seed, stream, &lc, &slot))) return rc;

@@ -109,7 +109,10 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         const LaneJob job0 = lane_job<PROBE>(work, 0u, cam, prm, probe_xys, n_probe);
         const uint32_t blk_log2 = PROBE ? 3u : prm.block_log2, blk_mask = (1u << blk_log2) - 1u;
         const uint32_t s_prefix = PROBE ? 0u : prm.sample_prefix_digits;
-        if (!PROBE && prm.sampler == 1u && sobol_hi_first(prm.log2_spp, blk_log2) - s_prefix < prm.n_base4_digits) {
+        // (the tables hold the permuted prefix in 27 bits per entry: a launch shape whose prefix is wider hashes every digit instead)
+        const uint32_t hi_first_w = sobol_hi_first(prm.log2_spp, blk_log2) - s_prefix, hi_shift_w = 2u * hi_first_w - (prm.log2_spp & 1u);
+        if (!PROBE && prm.sampler == 1u && hi_first_w < prm.n_base4_digits && hi_first_w >= 3u &&
+            2u * prm.n_base4_digits - (prm.log2_spp & 1u) <= hi_shift_w + 27u) {
             // block-uniform Sobol digit prefixes: lane d computes dimension d for this block (lane 0's pixel is the block origin).
             // Single-pixel items over an aligned 4^m block of sample indices: the sample digits above m are part of the prefix.
             sctx.hi_first = sobol_hi_first(prm.log2_spp, blk_log2) - s_prefix;
