@@ -339,7 +339,8 @@ def test_shards_tile_the_frame(product, pkg):
 
 
 @pytest.mark.parametrize("scene_id,w,h,spp", [(3, 160, 104, 1024), (8, 100, 70, 256), (0, 64, 48, 4096), (0, 40, 24, 16384),
-                                               (0, 8, 16384, 4096)])   # 38-bit sample indices: the prefix tables force a 2x2 block
+                                               (0, 8, 16384, 4096),    # 38-bit sample indices: the prefix tables force a 2x2 block
+                                               (3, 96, 64, 512), (0, 64, 48, 2048)])   # odd log2(spp): the half digit at the bottom of the index
 def test_launch_shape_does_not_change_the_frame(product, oracle, pkg, scene_id, w, h, spp):
     """The launcher picks the work-item shape from the number of sample indices per launch (8x8 tiles for short launches,
     4x4 / 2x2 / 1x1 pixel blocks for longer ones, api.cpp): the film of the whole job in ONE launch must equal the film
