@@ -6,9 +6,9 @@
 //
 //   DevNode      64 B  BVH2 node holding BOTH child boxes + child links      (SURVEY §8d "node 64 B")
 //   DevTri       48 B  render-space triangle, leaf order                     (36 B of positions + pad)
-//   DevTriShade  96 B  per-triangle shading attributes, fetched once per closest hit
+//   DevTriShade 112 B  per-triangle shading attributes + geometric normal, fetched once per closest hit
 //   DevMaterial  96 B  tagged material record
-//   DevLightTri  48 B  emissive triangle (render space) + area CDF entry
+//   DevLightTri  64 B  emissive triangle (render space) + area CDF entry + normal
 //   LUTs         470 f32 each; CIE x/y/z interleaved as float4 per nm
 //   rgb2spec     [3][64][64][64] float4 (c0,c1,c2,0) + 64 z nodes
 //   textures     RGBA8 (one dword per texel)
@@ -59,8 +59,10 @@ struct alignas(16) DevTriShade {
     uint32_t light;                // light index if emissive else ~0
     uint32_t local_tri;            // triangle index inside its mesh
     float light_pdf_area;          // (1/area_i) * (cdf_i - cdf_{i-1}) for emissive tris (emissive_triangle_mesh.rs:334-353)
+    float ng[3]; uint32_t pad_ng;  // RENDER-space geometric normal, normalize(normalize(cross(p1-p0, p2-p0))) (ray.rs:167-174): a function of
+                                   // the triangle alone, computed once by the host with the arithmetic of the device code it replaces
 };
-static_assert(sizeof(DevTriShade) == 96, "shade record must be 96 B");
+static_assert(sizeof(DevTriShade) == 112, "shade record must be 112 B");
 
 struct alignas(16) DevInstance {
     float lin[9];      // linear part of local_to_render, column-major 3x3 (vectors)
@@ -100,9 +102,10 @@ struct alignas(16) DevLightTri {
     float p0[3]; float p1x;
     float p1yz[2]; float p2xy[2];
     float p2z; float cdf;   // area_table entry (normalised running sum)
-    uint32_t pad[2];
+    float n[3];             // geometric normal of the triangle (emissive_triangle_mesh.rs:213-221), precomputed like DevTriShade::ng
+    uint32_t pad[3];
 };
-static_assert(sizeof(DevLightTri) == 48, "light tri");
+static_assert(sizeof(DevLightTri) == 64, "light tri");
 
 enum : uint32_t { LK_AREA = 0, LK_POINT = 1, LK_SPOT = 2, LK_DIRECTIONAL = 3, LK_ENV = 4 };
 struct alignas(16) DevLight {

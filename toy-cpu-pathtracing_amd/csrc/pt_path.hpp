@@ -46,9 +46,9 @@ PT_DEV Surface load_surface(const DevScene& sc, const Hit& h) {
     Surface s;
     TriVerts tv = load_tri(sc.tris, h.tri);
     s.p = tv.p0 * h.b0 + tv.p1 * h.b1 + tv.p2 * h.b2;                               // ray.rs:161-165
-    s.ng = normalize(normalize(cross(tv.p1 - tv.p0, tv.p2 - tv.p0)));                // ray.rs:167-174
     const float4* q = (const float4*)(sc.shade + h.tri);
-    float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
+    float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
+    s.ng = mk3(g.x, g.y, g.z);                                                       // ray.rs:167-174, precomputed per triangle (layout.hpp)
     f3 n0 = mk3(a.x, a.y, a.z), n1 = mk3(a.w, b.x, b.y), n2 = mk3(b.z, b.w, c.x);
     f3 tan_l = mk3(c.y, c.z, c.w);
     s.material = __float_as_uint(e.z);
@@ -751,13 +751,13 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     for (uint32_t k = 0; k < lt.n_tris; ++k) cnt += (s1 < sc.light_tris[lt.first_tri + k].cdf) ? 0u : 1u;
                     uint32_t tsel = cnt < lt.n_tris ? cnt : 0u;
                     const float4* q = (const float4*)(sc.light_tris + lt.first_tri + tsel);
-                    float4 qa = q[0], qb = q[1], qc = q[2];
+                    float4 qa = q[0], qb = q[1], qc = q[2], qd = q[3];
                     f3 p0 = mk3(qa.x, qa.y, qa.z), p1 = mk3(qa.w, qb.x, qb.y), p2 = mk3(qb.z, qb.w, qc.x);
                     float b0, b1;
                     if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
                     float b2 = 1.0f - b0 - b1;
                     f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
-                    ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
+                    ln = mk3(qc.z, qc.w, qd.x);                                  // normalize(normalize(cross(p1 - p0, p2 - p0))), precomputed
                     pdf_a = 1.0f / lt.area_sum;
                     dv = lp - sf.p;
                     wi_r = normalize(dv);
@@ -1484,13 +1484,13 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                     for (uint32_t k = 0; k < lt.n_tris; ++k) cnt += (s1 < sc.light_tris[lt.first_tri + k].cdf) ? 0u : 1u;
                     uint32_t tsel = cnt < lt.n_tris ? cnt : 0u;
                     const float4* q = (const float4*)(sc.light_tris + lt.first_tri + tsel);
-                    float4 qa = q[0], qb = q[1], qc = q[2];
+                    float4 qa = q[0], qb = q[1], qc = q[2], qd = q[3];
                     f3 p0 = mk3(qa.x, qa.y, qa.z), p1 = mk3(qa.w, qb.x, qb.y), p2 = mk3(qb.z, qb.w, qc.x);
                     float b0, b1;
                     if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
                     float b2 = 1.0f - b0 - b1;
                     f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
-                    ln = normalize(normalize(cross(p1 - p0, p2 - p0)));
+                    ln = mk3(qc.z, qc.w, qd.x);                                  // normalize(normalize(cross(p1 - p0, p2 - p0))), precomputed
                     pdf_a = 1.0f / lt.area_sum;
                     dv = lp - sf.p;
                     wi_r = normalize(dv);

@@ -240,6 +240,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             }
             btris.push_back(bt);
             DevTriShade sh{};
+            { V3 g = normalize(normalize(cross(p[1] - p[0], p[2] - p[0]))); sh.ng[0] = g.x; sh.ng[1] = g.y; sh.ng[2] = g.z; sh.pad_ng = 0; }
             const float* n0 = &mesh.nrm[3 * vi[0]]; const float* n1 = &mesh.nrm[3 * vi[1]]; const float* n2 = &mesh.nrm[3 * vi[2]];
             sh.n0[0] = n0[0]; sh.n0[1] = n0[1]; sh.n0[2] = n0[2]; sh.n1x = n1[0];
             sh.n1yz[0] = n1[1]; sh.n1yz[1] = n1[2]; sh.n2xy[0] = n2[0]; sh.n2xy[1] = n2[1]; sh.n2z = n2[2];
@@ -264,6 +265,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
                 lt.p0[0] = q[0].x; lt.p0[1] = q[0].y; lt.p0[2] = q[0].z; lt.p1x = q[1].x;
                 lt.p1yz[0] = q[1].y; lt.p1yz[1] = q[1].z; lt.p2xy[0] = q[2].x; lt.p2xy[1] = q[2].y; lt.p2z = q[2].z;
                 lt.cdf = area_table[t];
+                { V3 g = normalize(normalize(cross(q[1] - q[0], q[2] - q[0]))); lt.n[0] = g.x; lt.n[1] = g.y; lt.n[2] = g.z; }
                 light_tris.push_back(lt);
             }
             shade_unordered.push_back(sh);
