@@ -327,8 +327,9 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 float ur = get_1d(smp, sctx);
                 if (ur < p) {
                     if (p != 0.0f) {
+                        const float rp = 1.0f / p;       // one division instead of four (<= 1 ulp from T / p; radiance only)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) T[i] = T[i] / p;
+                        for (int i = 0; i < 4; ++i) T[i] = T[i] * rp;
                     }
                 } else end_path = true;
             }
@@ -401,9 +402,9 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         f3 w = to_world(nf, wi);
                         float gwi = dot(ng_t, w);
                         if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) {
-                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) / PI_F;
+                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) * INV_PI_F;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = albedo[i] * fabsf(wi.z) / PI_F;
+                            for (int i = 0; i < 4; ++i) s_f[i] = (albedo[i] * fabsf(wi.z)) * INV_PI_F;
                         }
                     }
                 }
@@ -824,9 +825,9 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         }
                     } else if (!(FEAT & FEAT_CC) || nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
                         if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
-                            pdf_b = fabsf(wi_nm.z) / PI_F;
+                            pdf_b = fabsf(wi_nm.z) * INV_PI_F;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) fl[i] = albedo[i] * fabsf(wi_nm.z) / PI_F;
+                            for (int i = 0; i < 4; ++i) fl[i] = (albedo[i] * fabsf(wi_nm.z)) * INV_PI_F;
                         }
                     } else {                                                  // SimpleClearcoatPbrMaterial::{evaluate,pdf} (:261-433)
                         float dgc, p5c, pdfc, dgb, p5b, pdfb;
@@ -1029,8 +1030,9 @@ PT_DEV bool shade_vertex_a(Path& P, const DevScene& sc, const DevParams& prm, co
                 float ur = get_1d(smp, sctx);
                 if (ur < p) {
                     if (p != 0.0f) {
+                        const float rp = 1.0f / p;       // one division instead of four (<= 1 ulp from T / p; radiance only)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) T[i] = T[i] / p;
+                        for (int i = 0; i < 4; ++i) T[i] = T[i] * rp;
                     }
                 } else end_path = true;
             }
@@ -1143,9 +1145,9 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                         f3 w = to_world(nf, wi);
                         float gwi = dot(ng_t, w);
                         if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) {
-                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) / PI_F;
+                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) * INV_PI_F;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = albedo[i] * fabsf(wi.z) / PI_F;
+                            for (int i = 0; i < 4; ++i) s_f[i] = (albedo[i] * fabsf(wi.z)) * INV_PI_F;
                         }
                     }
                 }
@@ -1557,9 +1559,9 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                         }
                     } else if (!(FEAT & FEAT_CC) || nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
                         if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
-                            pdf_b = fabsf(wi_nm.z) / PI_F;
+                            pdf_b = fabsf(wi_nm.z) * INV_PI_F;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) fl[i] = albedo[i] * fabsf(wi_nm.z) / PI_F;
+                            for (int i = 0; i < 4; ++i) fl[i] = (albedo[i] * fabsf(wi_nm.z)) * INV_PI_F;
                         }
                     } else {                                                  // SimpleClearcoatPbrMaterial::{evaluate,pdf} (:261-433)
                         float dgc, p5c, pdfc, dgb, p5b, pdfb;
