@@ -881,9 +881,10 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                     float g = fabsf(dot(ln_t, -wi_t)) / dist2;
                     float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
                     sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
+                    const float rden = 1.0f / (pdf_a * lprob);   // one division for the four wavelengths (<= 1 ulp from x / (pdf_a * lprob))
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        sh_c[i] = (T[i] * ((fl[i] * (lrad[i] * lm->intensity)) * g / (pdf_a * lprob))) * wgt;
+                        sh_c[i] = (T[i] * (((fl[i] * (lrad[i] * lm->intensity)) * g) * rden)) * wgt;
                     }
                 }
             }
@@ -1615,9 +1616,10 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                     float g = fabsf(dot(ln_t, -wi_t)) / dist2;
                     float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
                     sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
+                    const float rden = 1.0f / (pdf_a * lprob);   // one division for the four wavelengths (<= 1 ulp from x / (pdf_a * lprob))
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        sh_c[i] = (T[i] * ((fl[i] * (lrad[i] * lm->intensity)) * g / (pdf_a * lprob))) * wgt;
+                        sh_c[i] = (T[i] * (((fl[i] * (lrad[i] * lm->intensity)) * g) * rden)) * wgt;
                     }
                 }
             }
