@@ -142,7 +142,8 @@ PT_DEV void env_sample(const DevScene& sc, f2 uv, f3& wi, float& pdf_dir) {     
     uint32_t x = env_sample_cdf(sc.env.conditional + (size_t)y * w, w, uv.y);
     float u = ((float)x + 0.5f) / (float)w, v = ((float)y + 0.5f) / (float)h;
     float theta = v * PI_F, phi = u * 2.0f * PI_F;
-    f3 wl = mk3(sinf(theta) * cosf(phi), cosf(theta), sinf(theta) * sinf(phi));
+    float s_t, c_t, s_p, c_p; sincosf(theta, &s_t, &c_t); sincosf(phi, &s_p, &c_p);
+    f3 wl = mk3(s_t * c_p, c_t, s_t * s_p);
     wi = mat3_mul(sc.env.l2r, wl);
     pdf_dir = env_pdf(sc, wi);
 }
@@ -396,7 +397,8 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
                 if (wo_nm.z != 0.0f) {
                     float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                    f3 wi = mk3(r * cosf(th), r * sinf(th), sqrtf(1.0f - uv.x));
+                    float sn_th, cs_th; sincosf(th, &sn_th, &cs_th);                 // one range reduction for both (same values as sinf / cosf)
+                    f3 wi = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
                     if (wo_nm.z < 0.0f) wi.z = -wi.z;
                     if (wi.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi.z)) {
                         f3 w = to_world(nf, wi);
@@ -589,7 +591,8 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                             }
                         } else if (wo_nm.z != 0.0f) {
                             float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                            f3 w = mk3(r * cosf(th), r * sinf(th), sqrtf(1.0f - uv.x));
+                            float sn_th, cs_th; sincosf(th, &sn_th, &cs_th);
+                            f3 w = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
                             if (wo_nm.z < 0.0f) w.z = -w.z;
                             if (w.z != 0.0f && sgn1(wo_nm.z) == sgn1(w.z)) {
                                 okb = true; wi = w; pb = (fabsf(w.z) / PI_F) * (1.0f - frd);
@@ -1140,7 +1143,8 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                 eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
                 if (wo_nm.z != 0.0f) {
                     float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                    f3 wi = mk3(r * cosf(th), r * sinf(th), sqrtf(1.0f - uv.x));
+                    float sn_th, cs_th; sincosf(th, &sn_th, &cs_th);                 // one range reduction for both (same values as sinf / cosf)
+                    f3 wi = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
                     if (wo_nm.z < 0.0f) wi.z = -wi.z;
                     if (wi.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi.z)) {
                         f3 w = to_world(nf, wi);
@@ -1324,7 +1328,8 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                             }
                         } else if (wo_nm.z != 0.0f) {
                             float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                            f3 w = mk3(r * cosf(th), r * sinf(th), sqrtf(1.0f - uv.x));
+                            float sn_th, cs_th; sincosf(th, &sn_th, &cs_th);
+                            f3 w = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
                             if (wo_nm.z < 0.0f) w.z = -w.z;
                             if (w.z != 0.0f && sgn1(wo_nm.z) == sgn1(w.z)) {
                                 okb = true; wi = w; pb = (fabsf(w.z) / PI_F) * (1.0f - frd);
