@@ -247,7 +247,12 @@ PT_DEV void wl_init(Wl& w, float u) {
     }
     w.term = false;
 }
-PT_DEV float srgb_eotf_inverse(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
+// sRGB decode of a texture colour (eotf.rs:40-52 has c / 12.92 and ((c + 0.055) / 1.055).powf(2.4)).  The colour only selects
+// rgb2spec coefficients, a continuous map, so the hardware log2 / exp2 (relative error < 1e-6 on this range) replace the ~240 VALU
+// instructions of a correctly rounded powf, three times per textured lookup; the two constant divisions become multiplies.
+PT_DEV float srgb_eotf_inverse(float c) {
+    return c <= 0.04045f ? c * (1.0f / 12.92f) : __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf((c + 0.055f) * (1.0f / 1.055f)));
+}
 PT_DEV float lut_value(const float* lut, float lambda) {                 // densely_sampled_spectrum.rs:57-67
     if (!(lambda >= LAMBDA_MIN && lambda <= LAMBDA_MAX)) return 0.0f;
     int idx = (int)floorf(lambda - LAMBDA_MIN);
