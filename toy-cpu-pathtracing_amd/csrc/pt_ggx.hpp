@@ -13,19 +13,21 @@ PT_DEV float tan2_theta(f3 w) { float c2 = w.z * w.z; return c2 == 0.0f ? INFINI
 PT_DEV float cos_phi(f3 w) { float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f)); return st == 0.0f ? 1.0f : fminf(fmaxf(w.x / st, -1.0f), 1.0f); }
 PT_DEV float sin_phi(f3 w) { float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f)); return st == 0.0f ? 0.0f : fminf(fmaxf(w.y / st, -1.0f), 1.0f); }
 
+// Every material of the reference passes alpha_x == alpha_y (glass_material.rs:120-126, metal_material.rs, the clearcoat layers), and
+// then cos^2(phi)/ax^2 + sin^2(phi)/ay^2 is 1/alpha^2 up to the rounding of cos^2 + sin^2: the isotropic forms below differ from the
+// reference's anisotropic expressions by a few ulp in D and Lambda — factors of f and pdf, never of a direction — and save the two
+// sqrt + two divisions of cos_phi / sin_phi per evaluation (the coat albedo alone evaluates D and two Lambdas 64 times per vertex).
 PT_DEV float ggx_D(float ax, float ay, f3 wm) {                                   // generalized_schlick.rs:119-131
     float t2 = tan2_theta(wm);
     if (!isfinite(t2)) return 0.0f;
     float c2 = wm.z * wm.z, c4 = c2 * c2;
-    float cp = cos_phi(wm), sp = sin_phi(wm);
-    float e = t2 * ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay));
+    float e = t2 / (ax * ay);
     return 1.0f / (PI_F * ax * ay * c4 * ((1.0f + e) * (1.0f + e)));
 }
 PT_DEV float ggx_lambda(float ax, float ay, f3 w) {                               // :132-140
     float t2 = tan2_theta(w);
     if (isinf(t2)) return 0.0f;
-    float a = cos_phi(w) * ax, b = sin_phi(w) * ay;
-    return (sqrtf(1.0f + (a * a + b * b) * t2) - 1.0f) / 2.0f;
+    return (sqrtf(1.0f + (ax * ay) * t2) - 1.0f) / 2.0f;
 }
 PT_DEV float ggx_G(float ax, float ay, f3 wo, f3 wi) { return 1.0f / (1.0f + ggx_lambda(ax, ay, wo) + ggx_lambda(ax, ay, wi)); }
 PT_DEV float ggx_Dw(float ax, float ay, f3 w, f3 wm) {                            // :154-164
