@@ -1669,8 +1669,10 @@ PT_DEV void film_add(const Path& P, const DevScene& sc, const DevParams& prm, fl
             if (k == 0 || !wl.term) {
                 int idx = (int)floorf(wl.lam[k] - LAMBDA_MIN);
                 if (idx == 470) idx = 0;
-                float pdf = wl.term ? pdf0 / 4.0f : pdf0;
-                float c = L[k] / pdf / 4.0f;
+                // sensor.rs:52-66 divides by the wavelength pdf (1/470, or 1/1880 for a terminated sample) and by 4: the pdf is one of two
+                // constants, so its reciprocal is folded at compile time (<= 1 ulp from L / pdf)
+                const float inv_pdf = wl.term ? 1.0f / (pdf0 / 4.0f) : 1.0f / pdf0;
+                float c = (L[k] * inv_pdf) / 4.0f;
                 float4 m = cmf[idx];
                 X += c * m.x; Y += c * m.y; Z += c * m.z;
             }
