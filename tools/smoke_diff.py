@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""GPU box: where the smoke frame differs from the oracle, and how the difference behaves with more samples."""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+pkg = importlib.import_module("toy-cpu-pathtracing_amd")
+import ptoracle
+prod, orc = pkg.Product(), ptoracle.Oracle()
+pair = {}
+for name, be in (("gpu", prod), ("cpu", orc)):
+    sc = be.new_scene(); pair[name] = (sc, pkg.scenes.load_scene(sc, 3, 64, 48, tex_size=128))
+orc.set_faithful(pair["cpu"][0], False)
+for spp in (16, 64, 256):
+    prm = pkg.make_params(spp, "mis", "sobol")
+    g = prod.render(pair["gpu"][0], pair["gpu"][1], prm); c = orc.render(pair["cpu"][0], pair["cpu"][1], prm)
+    d = np.abs(g - c).max(axis=2)
+    ys, xs = np.where(d > 0.01)
+    print(f"spp {spp}: rmse {np.sqrt(np.mean((g - c) ** 2)):.5f} max {d.max():.4f} pixels>0.01: {len(ys)} {list(zip(xs[:5].tolist(), ys[:5].tolist()))}", flush=True)
+    if spp == 16 and len(ys):
+        x, y = int(xs[0]), int(ys[0])
+        xys = np.array([[x, y, s] for s in range(16)], np.uint32)
+        Lg, _, _ = pair["gpu"][0].probe_radiance(pair["gpu"][1], prm, xys); Lc, _, _ = pair["cpu"][0].probe_radiance(pair["cpu"][1], prm, xys)
+        bad = np.where(np.abs(Lg - Lc).max(axis=1) > 1e-3 * np.abs(Lc).max(axis=1) + 1e-4)[0]
+        print("  samples of that pixel that differ (probe path, exact kernel variant FEAT_ALL):", bad.tolist(), Lg[bad].tolist(), Lc[bad].tolist())

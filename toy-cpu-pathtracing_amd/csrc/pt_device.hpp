@@ -28,8 +28,9 @@ PT_DEV float sgn1(float x) { return copysignf(1.0f, x); }       // f32::signum f
 PT_DEV float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 
 constexpr float PI_F = 3.14159265358979323846f;
-// Lambert f and pdf multiply by 1/pi instead of dividing by pi (the reference divides): <= 1 ulp apart, on radiance values only —
-// a correctly rounded f32 division costs ~10 VALU instructions and these run nine times per path vertex
+// The light-connection EVALUATION of the Lambert f and pdf multiplies by 1/pi instead of dividing by pi (the reference divides):
+// <= 1 ulp apart, on contribution / MIS-weight values only.  The SAMPLED f and pdf keep the division: they form the throughput, and
+// for an albedo of exactly 1 the product f * (1 / pdf) decides whether the next vertex plays Russian roulette at all (p >= 1)
 constexpr float INV_PI_F = 0.31830988618379067154f;
 constexpr float LAMBDA_MIN = 360.0f, LAMBDA_MAX = 830.0f;
 

@@ -328,9 +328,10 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                 float ur = get_1d(smp, sctx);
                 if (ur < p) {
                     if (p != 0.0f) {
-                        const float rp = 1.0f / p;       // one division instead of four (<= 1 ulp from T / p; radiance only)
+                        // four divisions, not one reciprocal: T_max / p must be exactly 1 so that the next vertex skips its roulette
+                        // draw like the reference does (x * (1/x) can be 0.99999994, and a draw more shifts every later dimension)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) T[i] = T[i] * rp;
+                        for (int i = 0; i < 4; ++i) T[i] = T[i] / p;
                     }
                 } else end_path = true;
             }
@@ -404,9 +405,9 @@ PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, cons
                         f3 w = to_world(nf, wi);
                         float gwi = dot(ng_t, w);
                         if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) {
-                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) * INV_PI_F;
+                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) / PI_F;   // sampled f and pdf stay IEEE: for albedo 1 their ratio must round like the reference's (the `p >= 1` roulette gate)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = (albedo[i] * fabsf(wi.z)) * INV_PI_F;
+                            for (int i = 0; i < 4; ++i) s_f[i] = albedo[i] * fabsf(wi.z) / PI_F;
                         }
                     }
                 }
@@ -1034,9 +1035,10 @@ PT_DEV bool shade_vertex_a(Path& P, const DevScene& sc, const DevParams& prm, co
                 float ur = get_1d(smp, sctx);
                 if (ur < p) {
                     if (p != 0.0f) {
-                        const float rp = 1.0f / p;       // one division instead of four (<= 1 ulp from T / p; radiance only)
+                        // four divisions, not one reciprocal: T_max / p must be exactly 1 so that the next vertex skips its roulette
+                        // draw like the reference does (x * (1/x) can be 0.99999994, and a draw more shifts every later dimension)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) T[i] = T[i] * rp;
+                        for (int i = 0; i < 4; ++i) T[i] = T[i] / p;
                     }
                 } else end_path = true;
             }
@@ -1150,9 +1152,9 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
                         f3 w = to_world(nf, wi);
                         float gwi = dot(ng_t, w);
                         if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) {
-                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) * INV_PI_F;
+                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) / PI_F;   // sampled f and pdf stay IEEE: for albedo 1 their ratio must round like the reference's (the `p >= 1` roulette gate)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = (albedo[i] * fabsf(wi.z)) * INV_PI_F;
+                            for (int i = 0; i < 4; ++i) s_f[i] = albedo[i] * fabsf(wi.z) / PI_F;
                         }
                     }
                 }
