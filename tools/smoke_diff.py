@@ -7,16 +7,18 @@ import numpy as np
 pkg = importlib.import_module("toy-cpu-pathtracing_amd")
 import ptoracle
 prod, orc = pkg.Product(), ptoracle.Oracle()
+SID = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+STRAT = sys.argv[2] if len(sys.argv) > 2 else "mis"
 pair = {}
 for name, be in (("gpu", prod), ("cpu", orc)):
-    sc = be.new_scene(); pair[name] = (sc, pkg.scenes.load_scene(sc, 3, 64, 48, tex_size=128))
+    sc = be.new_scene(); pair[name] = (sc, pkg.scenes.load_scene(sc, SID, 64, 48, tex_size=128))
 orc.set_faithful(pair["cpu"][0], False)
 for spp in (16, 64, 256):
-    prm = pkg.make_params(spp, "mis", "sobol")
+    prm = pkg.make_params(spp, STRAT, "sobol")
     g = prod.render(pair["gpu"][0], pair["gpu"][1], prm); c = orc.render(pair["cpu"][0], pair["cpu"][1], prm)
     d = np.abs(g - c).max(axis=2)
     ys, xs = np.where(d > 0.01)
-    print(f"spp {spp}: rmse {np.sqrt(np.mean((g - c) ** 2)):.5f} max {d.max():.4f} pixels>0.01: {len(ys)} {list(zip(xs[:5].tolist(), ys[:5].tolist()))}", flush=True)
+    print(f"scene {SID} {STRAT} spp {spp}: rmse {np.sqrt(np.mean((g - c) ** 2)):.5f} max {d.max():.4f} pixels>0.01: {len(ys)} {list(zip(xs[:5].tolist(), ys[:5].tolist()))}", flush=True)
     if spp == 16 and len(ys):
         x, y = int(xs[0]), int(ys[0])
         xys = np.array([[x, y, s] for s in range(16)], np.uint32)

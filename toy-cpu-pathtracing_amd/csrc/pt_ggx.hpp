@@ -13,21 +13,23 @@ PT_DEV float tan2_theta(f3 w) { float c2 = w.z * w.z; return c2 == 0.0f ? INFINI
 PT_DEV float cos_phi(f3 w) { float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f)); return st == 0.0f ? 1.0f : fminf(fmaxf(w.x / st, -1.0f), 1.0f); }
 PT_DEV float sin_phi(f3 w) { float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f)); return st == 0.0f ? 0.0f : fminf(fmaxf(w.y / st, -1.0f), 1.0f); }
 
-// Every material of the reference passes alpha_x == alpha_y (glass_material.rs:120-126, metal_material.rs, the clearcoat layers), and
-// then cos^2(phi)/ax^2 + sin^2(phi)/ay^2 is 1/alpha^2 up to the rounding of cos^2 + sin^2: the isotropic forms below differ from the
-// reference's anisotropic expressions by a few ulp in D and Lambda — factors of f and pdf, never of a direction — and save the two
-// sqrt + two divisions of cos_phi / sin_phi per evaluation (the coat albedo alone evaluates D and two Lambdas 64 times per vertex).
+// Every material of the reference passes alpha_x == alpha_y (glass_material.rs:120-126, metal_material.rs, the clearcoat layers).
+// The anisotropic expressions then reduce to tan^2(theta) (cos^2(phi) + sin^2(phi)) / alpha^2 with cos(phi) = x / sin(theta),
+// sin(phi) = y / sin(theta): numerically that is (x^2 + y^2) / (z^2 alpha^2) — the (1 - z^2) of tan^2 and the sin^2(theta) under cos / sin
+// cancel, rounding error included.  The isotropic forms below compute exactly that quotient, so they stay within a few ulp of the
+// reference everywhere (using (1 - z^2) / z^2 instead drifts by up to 1e-4 near the normal, where 1 - z^2 cancels: enough to flip
+// Russian-roulette decisions in 4e-4 of the samples of a rough-metal scene), and save the two sqrt + two divisions of cos_phi / sin_phi
+// per evaluation (the coat albedo alone evaluates D and two Lambdas 64 times per vertex).
+PT_DEV float tan2_theta_xy(f3 w) { float c2 = w.z * w.z; return c2 == 0.0f ? INFINITY : (w.x * w.x + w.y * w.y) / c2; }
 PT_DEV float ggx_D(float ax, float ay, f3 wm) {                                   // generalized_schlick.rs:119-131
-    float t2 = tan2_theta(wm);
-    if (!isfinite(t2)) return 0.0f;
+    if (!isfinite(tan2_theta(wm))) return 0.0f;
     float c2 = wm.z * wm.z, c4 = c2 * c2;
-    float e = t2 / (ax * ay);
+    float e = tan2_theta_xy(wm) / (ax * ay);
     return 1.0f / (PI_F * ax * ay * c4 * ((1.0f + e) * (1.0f + e)));
 }
 PT_DEV float ggx_lambda(float ax, float ay, f3 w) {                               // :132-140
-    float t2 = tan2_theta(w);
-    if (isinf(t2)) return 0.0f;
-    return (sqrtf(1.0f + (ax * ay) * t2) - 1.0f) / 2.0f;
+    if (isinf(tan2_theta(w))) return 0.0f;
+    return (sqrtf(1.0f + (ax * ay) * tan2_theta_xy(w)) - 1.0f) / 2.0f;
 }
 PT_DEV float ggx_G(float ax, float ay, f3 wo, f3 wi) { return 1.0f / (1.0f + ggx_lambda(ax, ay, wo) + ggx_lambda(ax, ay, wi)); }
 PT_DEV float ggx_Dw(float ax, float ay, f3 w, f3 wm) {                            // :154-164
@@ -134,13 +136,13 @@ PT_DEV f3 est_normalize(f3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }
 PT_DEV float est_lambda(float a2, f3 w) {
     float c2 = w.z * w.z;
     if (c2 == 0.0f) return 0.0f;
-    float t2 = (1.0f - c2) * __builtin_amdgcn_rcpf(c2);
+    float t2 = (w.x * w.x + w.y * w.y) * __builtin_amdgcn_rcpf(c2);
     return (__builtin_amdgcn_sqrtf(1.0f + a2 * t2) - 1.0f) * 0.5f;
 }
 PT_DEV float est_D(float a2, f3 wm) {
     float c2 = wm.z * wm.z;
     if (c2 == 0.0f) return 0.0f;
-    float e = ((1.0f - c2) * __builtin_amdgcn_rcpf(c2)) * __builtin_amdgcn_rcpf(a2);
+    float e = ((wm.x * wm.x + wm.y * wm.y) * __builtin_amdgcn_rcpf(c2)) * __builtin_amdgcn_rcpf(a2);
     return __builtin_amdgcn_rcpf(PI_F * a2 * (c2 * c2) * ((1.0f + e) * (1.0f + e)));
 }
 PT_DEV GsSample gs_sample_R_estimate(float alpha, f3 wo, f2 uv) {
