@@ -172,7 +172,10 @@ int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const
 enum { MI355PT_BVH_AUTO = 0, MI355PT_BVH_HOST = 1, MI355PT_BVH_GPU = 2 };
 int mi355pt_scene_set_bvh_builder(mi355pt_scene* s, int mode);
 /* Scene::build(&camera): world->render translation, BVH build, light list; uploads to the current HIP device.
- * scene.rs:64-76 */
+ * scene.rs:64-76.  The camera POSITION is baked into the device records (render space = world - position,
+ * camera.rs:84-86): every later render call must pass the same position (direction, up, fov and size are free) and run
+ * with the same HIP device current, else it returns MI355PT_E_INVALID / MI355PT_E_DEVICE; move the camera = build again.
+ * Threading contract: one host thread and one stream at a time per scene (the scene owns its launch scratch). */
 int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam);
 
 /* Diagnostic: "nodes=.. tris=.. depth=.. builder=host|gpu bvh_ms=.. bvh_device_ms=.. features=.." of the built scene
@@ -207,7 +210,19 @@ int mi355pt_probe_intersect(const mi355pt_scene* s, const float* origins, const 
 /* Scene::intersect_p for n rays.  scene.rs:93-103 */
 int mi355pt_probe_occluded(const mi355pt_scene* s, const float* origins, const float* dirs, const float* t_max, uint32_t n,
                            uint8_t* out_hit);
-/* BaseSrgbRenderer::render's per-sample result before the sensor: L[4], lambda[4], pdf[4] for n (x,y,sample) queries */
+/* BaseSrgbRenderer::render's per-sample result before the sensor (base_renderer.rs:160-276: the L handed to
+ * Sensor::add_sample with its SampledWavelengths): L[4], lambda[4], pdf[4] for every finished path of a render call,
+ * written by the PRODUCTION kernel in the launch shape mi355pt_render_accum_device takes for the same arguments
+ * (a wave-uniform branch at path end; nothing else differs).  Record r = (k * 64 + (y & 7) * 8 + (x & 7)) *
+ * (sample_end - sample_begin) + (sample - sample_begin), k = position of the pixel's 8x8 tile among the tiles of the
+ * shard (tile t = shard_index + k * shard_count, row-major tiles); records of pixels outside the frame stay zero.
+ * Needs a power-of-two spp.  out_accum (host, W*H*3, NULL ok) receives the linear film sums of the same launch. */
+int mi355pt_sample_log_records(const mi355pt_camera* cam, const mi355pt_params* p, uint32_t sample_begin, uint32_t sample_end,
+                               size_t* out_records);
+int mi355pt_render_sample_log(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, uint32_t sample_begin,
+                              uint32_t sample_end, float* out_L, float* out_lambda, float* out_pdf, size_t n_records,
+                              float* out_accum);
+/* The same records picked for n (x, y, sample) queries of the whole-frame, whole-job launch (small frames only). */
 int mi355pt_probe_radiance(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, const uint32_t* xys,
                            uint32_t n, float* out_L, float* out_lambda, float* out_pdf);
 

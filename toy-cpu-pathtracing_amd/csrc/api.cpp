@@ -13,9 +13,9 @@
 #include "scene.hpp"
 
 namespace pt {
-hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, float*, unsigned*, DevStats*, bool, uint32_t, int, hipStream_t);
-hipError_t launch_probe_radiance(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, unsigned*, const uint32_t*, uint32_t, float*,
-                                 float*, float*, int, hipStream_t);
+struct PathOut { float* L; float* lam; float* pdf; uint32_t s_base, n_s; };   // per-sample log of a launch (pt_path.hpp)
+hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, float*, unsigned*, DevStats*, bool, uint32_t, int, hipStream_t,
+                     const PathOut&);
 hipError_t launch_resolve(const float*, uint32_t, uint32_t, float*, hipStream_t);
 hipError_t launch_probe_sobol(uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t*, hipStream_t);
 hipError_t launch_probe_intersect(const DevScene&, const float*, const float*, uint32_t, float*, uint32_t*, uint32_t*, float*, hipStream_t);
@@ -167,6 +167,13 @@ int check_args(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_
     if (cam->width == 0 || cam->height == 0 || p->spp == 0) return fail(MI355PT_E_INVALID, "empty image or spp == 0");
     if (p->strategy > 2 || p->sampler > 1) return fail(MI355PT_E_INVALID, "bad strategy/sampler");
     if (p->shard_count && p->shard_index >= p->shard_count) return fail(MI355PT_E_INVALID, "bad shard");
+    // mi355pt_scene_build bakes the world -> render translation (render space = world - camera position, camera.rs:84-86) into every
+    // device record and uploads to the device that was current then: a render call must name the same camera position and device
+    if (std::memcmp(cam->position, s->impl.build_cam_pos, sizeof(float) * 3) != 0)
+        return fail(MI355PT_E_INVALID, "camera position differs from the one given to mi355pt_scene_build: rebuild the scene");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != s->impl.device)
+        return fail(MI355PT_E_DEVICE, "current HIP device is not the device the scene was built on");
     return MI355PT_OK;
 }
 
@@ -339,8 +346,8 @@ int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam) {
 }
 
 static constexpr uint32_t PT_MAX_LAUNCH_SAMPLES = 4096;
-int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end,
-                                float* d_accum, void* hip_stream, mi355pt_stats* stats) {
+static int render_accum_range(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end,
+                              float* d_accum, void* hip_stream, mi355pt_stats* stats, const PathOut& pout) {
     int rc = check_args(s, cam, p);
     if (rc) return rc;
     if (!d_accum || s_end > p->spp || s_begin >= s_end) return fail(MI355PT_E_INVALID, "bad sample range or null accumulator");
@@ -349,7 +356,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
         // fewest digits per draw (the digits above the block join the prefix tables), and no launch runs for minutes
         for (uint32_t b = s_begin; b < s_end;) {
             const uint32_t e = std::min(s_end, (b / PT_MAX_LAUNCH_SAMPLES + 1u) * PT_MAX_LAUNCH_SAMPLES);
-            if ((rc = mi355pt_render_accum_device(s, cam, p, b, e, d_accum, hip_stream, nullptr))) return rc;
+            if ((rc = render_accum_range(s, cam, p, b, e, d_accum, hip_stream, nullptr, pout))) return rc;
             b = e;
         }
         return MI355PT_OK;
@@ -369,11 +376,15 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     uint32_t n_samples = s_end - s_begin;
     uint32_t block_log2 = 3;
     uint64_t PT_MIN_ITEM_SAMPLES = 2048;
-    if (const char* e = getenv("MI355PT_MIN_ITEM")) PT_MIN_ITEM_SAMPLES = (uint64_t)std::max(64, atoi(e));   // tuning experiment
+#ifdef MI355PT_TUNING   // launch-shape sweeps (tools/block_sweep.sh, chunk_sweep.sh): not in the shipped library
+    if (const char* e = getenv("MI355PT_MIN_ITEM")) PT_MIN_ITEM_SAMPLES = (uint64_t)std::max(64, atoi(e));
+#endif
     if (dp.sampler == MI355PT_SAMPLER_SOBOL) {
         while (block_log2 > 0 && ((uint64_t)n_samples << (2u * (block_log2 - 1u))) >= PT_MIN_ITEM_SAMPLES) --block_log2;
     }
-    if (const char* e = getenv("MI355PT_BLOCK")) { int b = atoi(e); if (b >= 0 && b <= 3) block_log2 = (uint32_t)b; }   // tuning experiment
+#ifdef MI355PT_TUNING
+    if (const char* e = getenv("MI355PT_BLOCK")) { int b = atoi(e); if (b >= 0 && b <= 3) block_log2 = (uint32_t)b; }
+#endif
     // the permuted block-uniform digits (everything above bit hi_shift of the 2 n - odd bit sample index) are packed into 27 bits
     // of a table word: large frames (>= 16384 pixels wide) need a larger block
     {
@@ -390,7 +401,9 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     uint32_t chunks = 1;
     while (n_items * chunks < (uint32_t)waves * 8 && chunks * 2 <= n_samples &&
            (n_samples / (chunks * 2)) >= (n_items * chunks >= (uint32_t)waves ? 16u : 8u)) chunks *= 2;
-    if (const char* e = getenv("MI355PT_CHUNKS")) { uint32_t c = (uint32_t)atoi(e); if (c >= 1 && c <= n_samples) chunks = c; }   // tuning experiment
+#ifdef MI355PT_TUNING
+    if (const char* e = getenv("MI355PT_CHUNKS")) { uint32_t c = (uint32_t)atoi(e); if (c >= 1 && c <= n_samples) chunks = c; }
+#endif
     dp.chunks = chunks; dp.chunk_size = (n_samples + chunks - 1) / chunks;
     dp.n_work = n_items * chunks;
     // single-pixel items whose sample ranges are aligned blocks of 4^m indices: the sample digits above m are item-uniform as well
@@ -422,7 +435,7 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
             lc->partial_floats = need;
         }
     }
-    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, lc->d_partial, d_counter, d_stats, want_stats, s->impl.features, grid, stream));
+    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, lc->d_partial, d_counter, d_stats, want_stats, s->impl.features, grid, stream, pout));
     if (stats) {
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(hipEventSynchronize(e1));
@@ -445,6 +458,48 @@ int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* ca
     return MI355PT_OK;   // stats == NULL: fully asynchronous on `stream`
 }
 
+int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end,
+                                float* d_accum, void* hip_stream, mi355pt_stats* stats) {
+    return render_accum_range(s, cam, p, s_begin, s_end, d_accum, hip_stream, stats, PathOut{nullptr, nullptr, nullptr, 0u, 0u});
+}
+
+// tiles of the frame that belong to the shard of `p`
+static uint32_t shard_tiles(const mi355pt_camera* cam, const mi355pt_params* p) {
+    const uint32_t total = ((cam->width + 7) / 8) * ((cam->height + 7) / 8);
+    const uint32_t cnt = p->shard_count ? p->shard_count : 1u, idx = p->shard_count ? p->shard_index : 0u;
+    return total > idx ? (total - idx + cnt - 1) / cnt : 0u;
+}
+
+int mi355pt_sample_log_records(const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end, size_t* out_records) {
+    if (!cam || !p || !out_records || s_end <= s_begin) return fail(MI355PT_E_INVALID, "bad argument");
+    *out_records = (size_t)shard_tiles(cam, p) * 64u * (s_end - s_begin);
+    return MI355PT_OK;
+}
+
+int mi355pt_render_sample_log(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, uint32_t s_begin, uint32_t s_end,
+                              float* out_L, float* out_lambda, float* out_pdf, size_t n_records, float* out_accum) {
+    int rc = check_args(s, cam, p);
+    if (rc) return rc;
+    if (!out_L || !out_lambda || !out_pdf || s_end > p->spp || s_begin >= s_end) return fail(MI355PT_E_INVALID, "bad sample range or null output");
+    if (p->spp & (p->spp - 1u)) return fail(MI355PT_E_INVALID, "the per-sample log needs a power-of-two spp (the sample index is read back from the Morton index)");
+    if (p->collect_stats) return fail(MI355PT_E_INVALID, "the per-sample log is written by the production kernel, not the instrumented one");
+    const size_t need = (size_t)shard_tiles(cam, p) * 64u * (s_end - s_begin);
+    if (n_records != need) return fail(MI355PT_E_INVALID, "n_records must be tiles of the shard * 64 * (sample_end - sample_begin)");
+    if (need == 0) return MI355PT_OK;
+    const size_t n_film = (size_t)cam->width * cam->height * 3;
+    DevBuf<float> d_L, d_lam, d_pdf, d_acc;
+    HIP_TRY(d_L.alloc(need * 4)); HIP_TRY(d_lam.alloc(need * 4)); HIP_TRY(d_pdf.alloc(need * 4)); HIP_TRY(d_acc.alloc(n_film));
+    HIP_TRY(hipMemset(d_L.p, 0, need * 16)); HIP_TRY(hipMemset(d_lam.p, 0, need * 16)); HIP_TRY(hipMemset(d_pdf.p, 0, need * 16));
+    HIP_TRY(hipMemset(d_acc.p, 0, n_film * sizeof(float)));
+    if ((rc = render_accum_range(s, cam, p, s_begin, s_end, d_acc.p, nullptr, nullptr, PathOut{d_L.p, d_lam.p, d_pdf.p, s_begin, s_end - s_begin}))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_L, d_L.p, need * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_lambda, d_lam.p, need * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_pdf, d_pdf.p, need * 16, hipMemcpyDeviceToHost));
+    if (out_accum) HIP_TRY(hipMemcpy(out_accum, d_acc.p, n_film * sizeof(float), hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+
 int mi355pt_scene_info(const mi355pt_scene* s, char* buf, size_t n) {
     if (!s || !buf || n == 0) return fail(MI355PT_E_INVALID, "null argument");
     if (!s->impl.built) return fail(MI355PT_E_INVALID, "scene not built");
@@ -462,15 +517,14 @@ int mi355pt_render(const mi355pt_scene* s, const mi355pt_camera* cam, const mi35
     if (rc) return rc;
     if (!out_rgb) return fail(MI355PT_E_INVALID, "null output");
     size_t n = (size_t)cam->width * cam->height * 3;
-    float *d_acc = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_acc, n * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&d_out, n * sizeof(float)));
-    HIP_TRY(hipMemset(d_acc, 0, n * sizeof(float)));
-    rc = mi355pt_render_accum_device(s, cam, p, 0, p->spp, d_acc, nullptr, stats);
-    if (!rc) rc = mi355pt_film_resolve_device(d_acc, cam->width * cam->height, p->spp, d_out, nullptr);
-    if (!rc) { hipError_t e = hipMemcpy(out_rgb, d_out, n * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI355PT_E_DEVICE, hipGetErrorString(e)); }
-    (void)hipFree(d_acc); (void)hipFree(d_out);
-    return rc;
+    DevBuf<float> d_acc, d_out;
+    HIP_TRY(d_acc.alloc(n));
+    HIP_TRY(d_out.alloc(n));
+    HIP_TRY(hipMemset(d_acc.p, 0, n * sizeof(float)));
+    if ((rc = mi355pt_render_accum_device(s, cam, p, 0, p->spp, d_acc.p, nullptr, stats))) return rc;
+    if ((rc = mi355pt_film_resolve_device(d_acc.p, cam->width * cam->height, p->spp, d_out.p, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(out_rgb, d_out.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return MI355PT_OK;
 }
 
 int mi355pt_quantize_u8(const float* rgb, size_t n, uint8_t* out) {
@@ -541,21 +595,22 @@ int mi355pt_probe_radiance(const mi355pt_scene* s, const mi355pt_camera* cam, co
     if (rc) return rc;
     if (!xys || !out_L || !out_lambda || !out_pdf) return fail(MI355PT_E_INVALID, "null argument");
     if (n == 0) return MI355PT_OK;
-    DevCamera dc = make_camera(cam);
-    DevParams dp = make_params(cam, p, 0, p->spp);
-    dp.chunks = 1; dp.chunk_size = 1; dp.block_log2 = 3; dp.sample_prefix_digits = 0; dp.n_work = (n + 63) / 64;
-    LaunchCtx* lc; int slot;
-    if ((rc = get_launch_ctx(s, p->seed, nullptr, &lc, &slot))) return rc;
-    HIP_TRY(hipMemset(lc->d_counters + slot, 0, sizeof(unsigned)));
-    DevBuf<uint32_t> d_xys; DevBuf<float> d_L, d_lam, d_pdf;
-    HIP_TRY(d_xys.alloc((size_t)n * 3)); HIP_TRY(d_L.alloc((size_t)n * 4)); HIP_TRY(d_lam.alloc((size_t)n * 4)); HIP_TRY(d_pdf.alloc((size_t)n * 4));
-    HIP_TRY(hipMemcpy(d_xys.p, xys, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice));
-    int grid = (int)std::min<uint32_t>(dp.n_work, (uint32_t)resident_waves((uint32_t)FEAT_ALL));
-    HIP_TRY(launch_probe_radiance(s->impl.dev, dc, dp, lc->d_hash, lc->d_counters + slot, d_xys.p, n, d_L.p, d_lam.p, d_pdf.p, grid, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out_L, d_L.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_lambda, d_lam.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_pdf, d_pdf.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+        if (xys[3 * i] >= cam->width || xys[3 * i + 1] >= cam->height || xys[3 * i + 2] >= p->spp) return fail(MI355PT_E_INVALID, "query outside the frame or the sample range");
+    // the whole frame, every sample index, in the launch shape mi355pt_render takes for this job — then pick the queried records
+    mi355pt_params q = *p;
+    q.shard_index = 0; q.shard_count = 1; q.collect_stats = 0;
+    const size_t recs = (size_t)shard_tiles(cam, &q) * 64u * p->spp;
+    if (recs > ((size_t)1 << 26)) return fail(MI355PT_E_INVALID, "frame x spp too large for mi355pt_probe_radiance: use mi355pt_render_sample_log on a sparse shard");
+    std::vector<float> L(recs * 4), lam(recs * 4), pdf(recs * 4);
+    if ((rc = mi355pt_render_sample_log(s, cam, &q, 0, p->spp, L.data(), lam.data(), pdf.data(), recs, nullptr))) return rc;
+    const uint32_t tiles_x = (cam->width + 7) / 8;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t x = xys[3 * i], y = xys[3 * i + 1], k = xys[3 * i + 2];
+        const size_t slot = ((size_t)((y / 8) * tiles_x + x / 8) * 64u + ((y & 7u) * 8u + (x & 7u))) * p->spp + k;
+        std::memcpy(out_L + 4 * (size_t)i, &L[4 * slot], 16); std::memcpy(out_lambda + 4 * (size_t)i, &lam[4 * slot], 16);
+        std::memcpy(out_pdf + 4 * (size_t)i, &pdf[4 * slot], 16);
+    }
     return MI355PT_OK;
 }
 

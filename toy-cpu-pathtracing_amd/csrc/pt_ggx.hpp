@@ -221,24 +221,6 @@ PT_DEV float coat_directional_albedo_coop(bool need, float alpha, float r0, f3 w
     }
     return result;
 }
-PT_DEV float coat_directional_albedo(float alpha, float r0, f3 wo, uint64_t key) {
-    float sum = 0.0f;
-    uint32_t n = 0;
-    for (int k = 0; k < 64; ++k) {
-        n += 1;   // uc: drawn, unused in mode R
-        uint64_t h1 = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(++n));
-        uint64_t h2 = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(++n));
-        f2 uv = f2{(float)(uint32_t)(h1 >> 40) * 5.9604644775390625e-8f, (float)(uint32_t)(h2 >> 40) * 5.9604644775390625e-8f};
-        GsSample s = gs_sample_R(alpha, wo, uv);
-        if (s.ok) {
-            float ci = fabsf(s.wi.z);
-            float f = (r0 + (1.0f - r0) * s.p5) * s.dg;
-            if (ci > 0.0f && s.pdf > 0.0f) sum += f * ci / s.pdf;
-        }
-    }
-    return sum / 64.0f;
-}
-
 // compute_attenuation (simple_pbr_clearcoat_material.rs:88-107) for one wavelength lane
 PT_DEV float cc_attenuation1(float tint, float thickness, float cos_theta) {
     float log_tint = logf(fmaxf(tint, 1e-10f));

@@ -16,26 +16,19 @@ namespace pt {
 #endif
 // work item -> lane assignment
 struct LaneJob { uint32_t px, py, s_cur, s_end; bool valid; };
-template <bool PROBE>
-PT_DEV LaneJob lane_job(uint32_t work, uint32_t lane, const DevCamera& cam, const DevParams& prm, const uint32_t* probe_xys, uint32_t n_probe) {
+PT_DEV LaneJob lane_job(uint32_t work, uint32_t lane, const DevCamera& cam, const DevParams& prm) {
     LaneJob j{0, 0, 0, 0, false};
-    if (PROBE) {
-        uint32_t qi = work * 64 + lane;
-        j.valid = qi < n_probe;
-        if (j.valid) { j.px = probe_xys[3 * qi]; j.py = probe_xys[3 * qi + 1]; j.s_cur = probe_xys[3 * qi + 2]; j.s_end = j.s_cur + 1; }
-    } else {
-        // work = ((tile * blocks per tile) + block) * chunks + chunk; lanes >= 4^b own no pixel of the block
-        const uint32_t b = prm.block_log2, bside = 1u << b;
-        uint32_t item = work / prm.chunks, chunk = work % prm.chunks;
-        uint32_t tile_k = item >> (6u - 2u * b), blk = item & ((64u >> (2u * b)) - 1u);
-        uint32_t tile = prm.shard_index + tile_k * prm.shard_count;
-        uint32_t tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
-        uint32_t bx = blk & ((8u >> b) - 1u), by = blk >> (3u - b);
-        j.px = tx * 8 + bx * bside + (lane & (bside - 1u)); j.py = ty * 8 + by * bside + ((lane >> b) & (bside - 1u));
-        j.valid = lane < (1u << (2u * b)) && j.px < cam.width && j.py < cam.height;
-        j.s_cur = prm.sample_begin + chunk * prm.chunk_size;
-        j.s_end = min(j.s_cur + prm.chunk_size, prm.sample_end);
-    }
+    // work = ((tile * blocks per tile) + block) * chunks + chunk; lanes >= 4^b own no pixel of the block
+    const uint32_t b = prm.block_log2, bside = 1u << b;
+    uint32_t item = work / prm.chunks, chunk = work % prm.chunks;
+    uint32_t tile_k = item >> (6u - 2u * b), blk = item & ((64u >> (2u * b)) - 1u);
+    uint32_t tile = prm.shard_index + tile_k * prm.shard_count;
+    uint32_t tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
+    uint32_t bx = blk & ((8u >> b) - 1u), by = blk >> (3u - b);
+    j.px = tx * 8 + bx * bside + (lane & (bside - 1u)); j.py = ty * 8 + by * bside + ((lane >> b) & (bside - 1u));
+    j.valid = lane < (1u << (2u * b)) && j.px < cam.width && j.py < cam.height;
+    j.s_cur = prm.sample_begin + chunk * prm.chunk_size;
+    j.s_end = min(j.s_cur + prm.chunk_size, prm.sample_end);
     return j;
 }
 
@@ -63,11 +56,10 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 // MODE compiles the renderer strategy and the sampler in (MODE_GENERIC reads them from DevParams): the branches on
 // prm.strategy / the sampler mode fold away, worth +2.5 % on C2 (MIS + Sobol), +1.3 % on C5 (NEE + Sobol).
 enum : uint32_t { MODE_GENERIC = 0, MODE_MIS_SOBOL = 1, MODE_NEE_SOBOL = 2 };
-template <bool STATS, bool PROBE, uint32_t FEAT, uint32_t MODE = MODE_GENERIC>
+template <bool STATS, uint32_t FEAT, uint32_t MODE = MODE_GENERIC>
 __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WAVES)) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm_in, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, float* __restrict__ partial, unsigned* __restrict__ work_counter,
-                                                DevStats* __restrict__ stats, const uint32_t* __restrict__ probe_xys, uint32_t n_probe,
-                                                PathOut pout) {
+                                                DevStats* __restrict__ stats, PathOut pout) {
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
     __shared__ float s_film[64 * 3];                 // the work item's 8x8 film tile
     __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
@@ -105,13 +97,13 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         __syncthreads();
         if (work >= prm.n_work) break;
         // this lane's own pixel of the tile (film write-back) and the work item's wave-uniform sample range
-        const LaneJob job = lane_job<PROBE>(work, lane, cam, prm, probe_xys, n_probe);
-        const LaneJob job0 = lane_job<PROBE>(work, 0u, cam, prm, probe_xys, n_probe);
-        const uint32_t blk_log2 = PROBE ? 3u : prm.block_log2, blk_mask = (1u << blk_log2) - 1u;
-        const uint32_t s_prefix = PROBE ? 0u : prm.sample_prefix_digits;
+        const LaneJob job = lane_job(work, lane, cam, prm);
+        const LaneJob job0 = lane_job(work, 0u, cam, prm);
+        const uint32_t blk_log2 = prm.block_log2, blk_mask = (1u << blk_log2) - 1u;
+        const uint32_t s_prefix = prm.sample_prefix_digits;
         // (the tables hold the permuted prefix in 27 bits per entry: a launch shape whose prefix is wider hashes every digit instead)
         const uint32_t hi_first_w = sobol_hi_first(prm.log2_spp, blk_log2) - s_prefix, hi_shift_w = 2u * hi_first_w - (prm.log2_spp & 1u);
-        if (!PROBE && prm.sampler == 1u && hi_first_w < prm.n_base4_digits && hi_first_w >= 3u &&
+        if (prm.sampler == 1u && hi_first_w < prm.n_base4_digits && hi_first_w >= 3u &&
             2u * prm.n_base4_digits - (prm.log2_spp & 1u) <= hi_shift_w + 27u) {
             // block-uniform Sobol digit prefixes: lane d computes dimension d for this block (lane 0's pixel is the block origin).
             // Single-pixel items over an aligned 4^m block of sample indices: the sample digits above m are part of the prefix.
@@ -133,7 +125,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         // tile's film lives in LDS (ds_add_f32); the hand-out order is a function of the wave's own deterministic schedule.
         s_film[3 * lane] = 0.0f; s_film[3 * lane + 1] = 0.0f; s_film[3 * lane + 2] = 0.0f;
         __syncthreads();
-        const uint32_t n_s = PROBE ? 1u : (job0.s_end > job0.s_cur ? job0.s_end - job0.s_cur : 0u);
+        const uint32_t n_s = job0.s_end > job0.s_cur ? job0.s_end - job0.s_cur : 0u;
         const uint32_t pool_size = n_s << (2u * blk_log2);
         uint32_t pool_next = 0u;                                   // wave-uniform
         uint32_t my_pix = lane;
@@ -147,16 +139,9 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 const uint32_t idx = pool_next + (uint32_t)__popcll(m_needy & ((1ull << lane) - 1ull));
                 if (!active && idx < pool_size) {
                     const uint32_t pix = idx & ((1u << (2u * blk_log2)) - 1u);
-                    uint32_t px, py, smp_i; bool valid;
-                    if (PROBE) {
-                        const uint32_t qi = work * 64u + pix;
-                        valid = qi < n_probe;
-                        px = valid ? probe_xys[3 * qi] : 0u; py = valid ? probe_xys[3 * qi + 1] : 0u; smp_i = valid ? probe_xys[3 * qi + 2] : 0u;
-                    } else {
-                        px = job0.px + (pix & blk_mask); py = job0.py + (pix >> blk_log2);
-                        smp_i = job0.s_cur + (idx >> (2u * blk_log2));
-                        valid = px < cam.width && py < cam.height;
-                    }
+                    const uint32_t px = job0.px + (pix & blk_mask), py = job0.py + (pix >> blk_log2);
+                    const uint32_t smp_i = job0.s_cur + (idx >> (2u * blk_log2));
+                    const bool valid = px < cam.width && py < cam.height;
                     if (valid) { active = true; my_pix = pix; regen_path<STATS>(P, sctx, cam, px, py, smp_i, st); }
                 }
                 pool_next = min(pool_next + (uint32_t)__popcll(m_needy), pool_size);
@@ -177,10 +162,10 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             if constexpr ((FEAT & FEAT_CC) != 0u) {
                 ShadeCtx C;
                 C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
-                if (active) end_path = shade_vertex_a<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, C);
+                if (active) end_path = shade_vertex_head<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, C);
                 // the coat's 64-sample directional albedo, estimated by the whole wave for the lanes that need it
                 C.cc_fc = coat_directional_albedo_coop(active && C.cont && C.need_cc, C.cc_alpha_c, C.cc_r0c, C.wo_nm, C.mc_key, lane);
-                if (active && C.cont) end_path = shade_vertex_b<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
+                if (active && C.cont) end_path = shade_vertex_tail<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
             } else {
                 if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
             }
@@ -217,12 +202,16 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
 #endif
             if (STATS) ts4 = __builtin_amdgcn_s_memtime();
             if (active && end_path) {
-                if (PROBE) { float a0 = 0, a1 = 0, a2 = 0; film_add<true>(P, sc, prm, a0, a1, a2, pout, work * 64u + my_pix); }
-                else {
-                    float r, g, b;
-                    film_rgb(P, sc, prm, r, g, b);
-                    atomicAdd(&s_film[3 * my_pix], r); atomicAdd(&s_film[3 * my_pix + 1], g); atomicAdd(&s_film[3 * my_pix + 2], b);
+                if (pout.L != nullptr) {
+                    // per-sample log (see PathOut): the sample index is the low log2(spp) bits of the lane's Morton index (spp a power of two)
+                    const uint32_t px = job0.px + (my_pix & blk_mask), py = job0.py + (my_pix >> blk_log2);
+                    const uint32_t tile_k = (work / prm.chunks) >> (6u - 2u * blk_log2);
+                    const uint32_t smp_i = P.smp.morton & ((1u << prm.log2_spp) - 1u);
+                    sample_log(P, pout, ((size_t)tile_k * 64u + ((py & 7u) * 8u + (px & 7u))) * pout.n_s + (smp_i - pout.s_base));
                 }
+                float r, g, b;
+                film_rgb(P, sc, prm, r, g, b);
+                atomicAdd(&s_film[3 * my_pix], r); atomicAdd(&s_film[3 * my_pix + 1], g); atomicAdd(&s_film[3 * my_pix + 2], b);
                 active = false;
             }
             if (STATS) {
@@ -232,7 +221,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             }
         }
         __syncthreads();
-        if (!PROBE && job.valid) {
+        if (job.valid) {
             size_t o = ((size_t)job.py * cam.width + job.px) * 3;
             const float fr = s_film[3 * lane], fg = s_film[3 * lane + 1], fb = s_film[3 * lane + 2];
             if (prm.chunks == 1) { accum[o] += fr; accum[o + 1] += fg; accum[o + 2] += fb; }
@@ -262,15 +251,14 @@ inline uint32_t pick_features(uint32_t feat) {
 }
 struct PtLaunchArgs {
     DevScene sc; DevCamera cam; DevParams prm; const uint64_t* d_hash; float* d_accum; float* d_partial; unsigned* d_counter; DevStats* d_stats;
-    int grid; hipStream_t stream;
+    int grid; hipStream_t stream; PathOut pout;
 };
 #define PT_FOR_EACH_FEATURE_SET(X) \
     X(0u) X(FEAT_TEX) X(FEAT_DIEL) X(FEAT_METAL) X(FEAT_DIEL | FEAT_ROUGH) X(FEAT_DELTA | FEAT_MLIGHT) X(FEAT_CC) X(FEAT_CC | FEAT_TEX) X(FEAT_ALL & ~FEAT_CC) X(FEAT_ALL)
 template <uint32_t MODE>
 void launch_pt_mode(const PtLaunchArgs& a, uint32_t feat) {
-    PathOut po{nullptr, nullptr, nullptr};
     switch (pick_features(feat)) {
-#define PT_CASE(F) case (F): hipLaunchKernelGGL((pt_kernel<false, false, (F), MODE>), dim3(a.grid), dim3(64), 0, a.stream, a.sc, a.cam, a.prm, a.d_hash, a.d_accum, a.d_partial, a.d_counter, a.d_stats, nullptr, 0u, po); break;
+#define PT_CASE(F) case (F): hipLaunchKernelGGL((pt_kernel<false, (F), MODE>), dim3(a.grid), dim3(64), 0, a.stream, a.sc, a.cam, a.prm, a.d_hash, a.d_accum, a.d_partial, a.d_counter, a.d_stats, a.pout); break;
         PT_FOR_EACH_FEATURE_SET(PT_CASE)
 #undef PT_CASE
     }
@@ -281,7 +269,7 @@ int occupancy_pt_mode(uint32_t feat) {
     int per_cu = 0;
     hipError_t e = hipErrorUnknown;
     switch (pick_features(feat)) {
-#define PT_CASE(F) case (F): e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, false, (F), MODE>, 64, 0); break;
+#define PT_CASE(F) case (F): e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, (F), MODE>, 64, 0); break;
         PT_FOR_EACH_FEATURE_SET(PT_CASE)
 #undef PT_CASE
     }

@@ -16,7 +16,7 @@
 //    sample of its pixel at the top of the next iteration.  Alternatives built and measured on MI355X:
 //    a lane pool with vote-driven batched shading (516 vs 654 Msamples/s), one merged shadow+closest traversal loop
 //    per iteration (670 vs 851), packed-f32 slab tests (-5 %): slower.  Persistent traversal with dynamic ray fetch
-//    (probe_intersect_dyn_kernel below, wave-local ray batches): 1.16-1.55x on the stand-alone traversal kernel for
+//    (experiments/probe_intersect_dyn.inc, wave-local ray batches): 1.16-1.55x on the stand-alone traversal kernel for
 //    incoherent rays, 0.6x for coherent ones — not enough to pay for streaming path state through HBM;
 //  * shadow rays use deferred, dense triangle tests (trace_any_deferred, pt_device.hpp): lanes only walk nodes and
 //    queue (triangle, lane) pairs in an LDS ring, the wave tests 64 pairs at a time (any-hit is order independent).
@@ -103,111 +103,9 @@ __global__ __launch_bounds__(64) void probe_occluded_kernel(DevScene sc, const f
 }
 
 
-// ---- experiment (MI355PT_TRAV=2, probe_intersect only): persistent traversal with dynamic ray fetch -----------------
-// Waves own a contiguous batch of rays (one global atomic per DYN_BATCH rays); a lane whose ray finished takes the next
-// ray of the batch, so the wave does not idle through the tail of its slowest ray.  Leaves are postponed until
-// DYN_LEAF_MIN lanes hold one (or nobody has a node left).
-#ifndef DYN_BATCH
-#define DYN_BATCH 1024u
+#ifdef PT_EXPERIMENTS
+#include "experiments/probe_intersect_dyn.inc"
 #endif
-#ifndef DYN_LEAF_MIN
-#define DYN_LEAF_MIN 16
-#endif
-#ifndef DYN_REFILL_MIN
-#define DYN_REFILL_MIN 12
-#endif
-#ifndef DYN_WAVES
-#define DYN_WAVES 8
-#endif
-__global__ __launch_bounds__(64, DYN_WAVES) void probe_intersect_dyn_kernel(DevScene sc, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
-                                                                 float* __restrict__ out_t, uint32_t* __restrict__ out_inst,
-                                                                 uint32_t* __restrict__ out_tri, unsigned* __restrict__ counter) {
-    __shared__ uint32_t s_stack[STACK_DEPTH * 64];
-    uint32_t* stack = s_stack + threadIdx.x;
-    const uint32_t lane = threadIdx.x;
-    bool have = false, pool_empty = false;
-    uint32_t next = 0, end = 0;          // wave-uniform: the batch this wave is serving
-    uint32_t ray = 0;
-    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
-    RaySetup rs{};
-    float t_best = 0.0f;
-    int32_t cur = 0; int sp = 0;
-    uint32_t best_tri = 0; bool found = false;
-    for (;;) {
-        // ---- refill: idle lanes take the next rays of the wave's batch ----
-        unsigned long long idle = __ballot(!have);
-        if (idle != 0ull) {
-            if (next >= end && !pool_empty) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(counter, DYN_BATCH);
-                base = __shfl(base, 0);
-                if (base >= n) pool_empty = true; else { next = base; end = min(base + DYN_BATCH, n); }
-            }
-            uint32_t avail = end - next;
-            if (avail != 0u) {
-                uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (!have && rank < avail) {
-                    uint32_t r = next + rank;
-                    ray = r; have = true;
-                    ro = mk3(o[3 * r], o[3 * r + 1], o[3 * r + 2]); rd = mk3(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
-                    rs = setup_ray(rd); t_best = 3.402823466e+38f; cur = sc.root; sp = 0; found = false;
-                }
-                next += min((uint32_t)__popcll(idle), avail);
-            }
-        }
-        if (__ballot(have) == 0ull) { if (pool_empty || next >= end) { if (pool_empty) break; } continue; }
-        // ---- traversal quantum ----
-        for (int q = 0; q < 32; ++q) {
-            bool fin = false;
-            if (have && cur >= 0) {
-                const float4* qn = (const float4*)(sc.nodes + cur);
-                float4 nx = qn[0], ny = qn[1], nz = qn[2];
-                int2 ch = *(const int2*)(qn + 3);
-                float l0x = (nx.x - ro.x) * rs.inv.x, h0x = (nx.z - ro.x) * rs.inv.x;
-                float l1x = (nx.y - ro.x) * rs.inv.x, h1x = (nx.w - ro.x) * rs.inv.x;
-                float l0y = (ny.x - ro.y) * rs.inv.y, h0y = (ny.z - ro.y) * rs.inv.y;
-                float l1y = (ny.y - ro.y) * rs.inv.y, h1y = (ny.w - ro.y) * rs.inv.y;
-                float l0z = (nz.x - ro.z) * rs.inv.z, h0z = (nz.z - ro.z) * rs.inv.z;
-                float l1z = (nz.y - ro.z) * rs.inv.z, h1z = (nz.w - ro.z) * rs.inv.z;
-                float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
-                float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), t_best));
-                float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
-                float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), t_best));
-                bool hit0 = n0 <= f0, hit1 = n1 <= f1;
-                if (hit0 && hit1) { bool first0 = n0 <= n1; stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp; cur = first0 ? ch.x : ch.y; }
-                else if (hit0) cur = ch.x;
-                else if (hit1) cur = ch.y;
-                else if (sp == 0) fin = true;
-                else { --sp; cur = (int32_t)stack[sp * 64]; }
-            }
-            const bool at_leaf = have && !fin && cur < 0;
-            const unsigned long long m_leaf = __ballot(at_leaf);
-            if (m_leaf != 0ull && (__popcll(m_leaf) >= DYN_LEAF_MIN || __ballot(have && !fin && cur >= 0) == 0ull)) {
-                if (at_leaf) {
-                    uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
-                    for (uint32_t i = 0; i < cnt; ++i) {
-                        TriVerts tv = load_tri(sc.tris, first + i);
-                        float t, b0, b1, b2;
-                        if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
-                            if (!found || t < t_best) { found = true; t_best = t; best_tri = first + i; }
-                        }
-                    }
-                    if (sp == 0) fin = true; else { --sp; cur = (int32_t)stack[sp * 64]; }
-                }
-            }
-            if (fin) {
-                const float4* qs = (const float4*)(sc.shade + best_tri);
-                out_t[ray] = found ? t_best : -1.0f;
-                out_inst[ray] = found ? __float_as_uint(qs[4].w) : 0xffffffffu;
-                out_tri[ray] = found ? __float_as_uint(qs[5].z) : 0xffffffffu;
-                have = false;
-            }
-            const unsigned long long m_have = __ballot(have);
-            if (m_have == 0ull) break;
-            if (64 - __popcll(m_have) >= DYN_REFILL_MIN && !(pool_empty && next >= end)) break;   // refill
-        }
-    }
-}
 
 // adds the per-chunk film tiles of a split launch to the film, in chunk order (one thread per pixel of each tile of the shard)
 __global__ void combine_kernel(DevCamera cam, DevParams prm, const float* __restrict__ partial, float* __restrict__ accum, uint32_t n_tiles) {
@@ -229,11 +127,10 @@ __global__ void combine_kernel(DevCamera cam, DevParams prm, const float* __rest
 // launch wrappers (host side, called from api.cpp)
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const uint64_t* d_hash, float* d_accum, float* d_partial,
-                     unsigned* d_counter, DevStats* d_stats, bool stats, uint32_t feat, int grid, hipStream_t stream) {
-    PathOut po{nullptr, nullptr, nullptr};
-    const PtLaunchArgs a{sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, grid, stream};
+                     unsigned* d_counter, DevStats* d_stats, bool stats, uint32_t feat, int grid, hipStream_t stream, const PathOut& pout) {
+    const PtLaunchArgs a{sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, grid, stream, pout};
     if (stats) {
-        hipLaunchKernelGGL((pt_kernel<true, false, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, nullptr, 0u, po);
+        hipLaunchKernelGGL((pt_kernel<true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout);
     } else if (prm.sampler == 1u && prm.strategy == 2u) launch_pt_mis_sobol(a, feat);
     else if (prm.sampler == 1u && prm.strategy == 1u) launch_pt_nee_sobol(a, feat);
     else launch_pt_mode<MODE_GENERIC>(a, feat);
@@ -241,12 +138,6 @@ hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& 
         const uint32_t n_tiles = (prm.n_work / prm.chunks) >> (6u - 2u * prm.block_log2);   // n_work = tiles * blocks per tile * chunks
         hipLaunchKernelGGL(combine_kernel, dim3(n_tiles), dim3(64), 0, stream, cam, prm, (const float*)d_partial, d_accum, n_tiles);
     }
-    return hipGetLastError();
-}
-hipError_t launch_probe_radiance(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const uint64_t* d_hash, unsigned* d_counter,
-                                 const uint32_t* d_xys, uint32_t n, float* d_L, float* d_lam, float* d_pdf, int grid, hipStream_t stream) {
-    PathOut po{d_L, d_lam, d_pdf};
-    hipLaunchKernelGGL((pt_kernel<false, true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, nullptr, nullptr, d_counter, nullptr, d_xys, n, po);
     return hipGetLastError();
 }
 hipError_t launch_resolve(const float* d_accum, uint32_t n_values, uint32_t spp, float* d_out, hipStream_t stream) {
@@ -261,6 +152,7 @@ hipError_t launch_probe_sobol(uint32_t width, uint32_t seed, uint32_t log2_spp, 
 }
 hipError_t launch_probe_intersect(const DevScene& sc, const float* o, const float* d, uint32_t n, float* t, uint32_t* inst, uint32_t* tri, float* nrm,
                                   hipStream_t stream) {
+#ifdef PT_EXPERIMENTS
     const char* mode = getenv("MI355PT_TRAV");
     if (mode && mode[0] == '2') {
         static unsigned* d_ctr = nullptr;
@@ -274,8 +166,8 @@ hipError_t launch_probe_intersect(const DevScene& sc, const float* o, const floa
         hipLaunchKernelGGL(probe_intersect_dyn_kernel, dim3(grid), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, d_ctr);
         return hipGetLastError();
     }
-    const char* lds = getenv("MI355PT_PROBE_LDS");   // experiment: extra dynamic LDS per wave to throttle occupancy
-    hipLaunchKernelGGL(probe_intersect_kernel, dim3((n + 63) / 64), dim3(64), lds ? atoi(lds) : 0, stream, sc, o, d, n, t, inst, tri, nrm);
+#endif
+    hipLaunchKernelGGL(probe_intersect_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, nrm);
     return hipGetLastError();
 }
 hipError_t launch_probe_occluded(const DevScene& sc, const float* o, const float* d, const float* tmax, uint32_t n, uint8_t* out, hipStream_t stream) {

@@ -216,707 +216,15 @@ PT_DEV void regen_path(Path& P, const SamplerCtx& sctx, const DevCamera& cam, ui
     (void)need_new;
 }
 
-// One path vertex: the closest-hit result of P.ro/P.rd arrives (got/hit).  Accounts emission (with the strategy's weight),
-// applies throughput + Russian roulette, samples the BSDF and the light.  Returns true when the path ends here; otherwise
-// P.ro/P.rd hold the next ray.  `sh` receives the light connection (it may be set even when the path ends).
-template <bool STATS, uint32_t FEAT>
-PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, bool got, const Hit& hit, ShadowReq& sh,
-                         StatCounters& st, unsigned long long& tsa, unsigned long long& tsb) {
-    Sampler& smp = P.smp; Wl& wl = P.wl; float* T = P.T; float* L = P.L; f3& ro = P.ro; f3& rd = P.rd;
-    bool& from_camera = P.from_camera; bool& prev_spec = P.prev_spec; float* pf = P.pf; float& p_pdf = P.p_pdf; f3& prev_pos = P.prev_pos;
-    uint32_t& depth = P.depth;
-    bool end_path = false;
-    bool& do_shadow = sh.on; f3& sh_o = sh.o; f3& sh_d = sh.d; float& sh_t = sh.t; float* sh_c = sh.c;
-    do_shadow = false;
-
-    if (!got) {
-        end_path = true;
-        if ((FEAT & FEAT_ENV) && sc.env.present) {
-            float rad[4];
-            env_radiance(sc, rd, wl, rad);
-            if (from_camera) {                                               // base_renderer.rs:180-187
-#pragma unroll
-                for (int i = 0; i < 4; ++i) L[i] = L[i] + T[i] * rad[i];
-            } else if (prm.strategy == 0u) {                                 // pt_renderer.rs:50-82: T * f * Le / pdf
-#pragma unroll
-                for (int i = 0; i < 4; ++i) L[i] = L[i] + sdiv((T[i] * pf[i]) * rad[i], p_pdf);
-            } else if (prm.strategy == 2u) {                                 // mis_renderer.rs:183-230 (also for specular samples)
-                // pdf_infinite_light_sample: probability among the INFINITE lights (1 with one environment light whose
-                // weight is non-zero, light_sampler.rs:115-153) times the direction pdf
-                float light_pdf = 1.0f * env_pdf(sc, rd);
-                float w = balance_heuristic(p_pdf, light_pdf);
-                float tf = 1.0f / p_pdf;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) L[i] = L[i] + ((((T[i] * pf[i]) * rad[i]) * tf) * w);
-            }                                                                // nee_renderer.rs:139-153: nothing
-        }
-    } else {
-        Surface sf = load_surface(sc, hit);
-        const DevMaterial* mat = sc.materials + sf.material;
-        const uint32_t mtype = mat->type;
-        const bool emissive = mtype == MT_EMISSIVE;
-        float Le[4] = {0, 0, 0, 0};
-        if (emissive) {                                                      // evaluate_emissive_surface :54-73
-            DevSpectrum rs = load_spectrum(&mat->color);
-            eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, rs, wl, sf.uv, Le, st);
-            float inten = mat->intensity;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) Le[i] = Le[i] * inten;
-        }
-        if (from_camera) {
-            if (emissive) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) L[i] = L[i] + T[i] * Le[i];      // :190-194
-            }
-        } else {
-            // calculate_bsdf_contribution (pt :33-47, nee :120-137, mis :151-181)
-            float tf = 1.0f / p_pdf;
-            if (emissive) {
-                float w = 1.0f;
-                if (prm.strategy == 1u) w = prev_spec ? 1.0f : 0.0f;
-                else if (prm.strategy == 2u && !prev_spec) {
-                    // Scene::pdf_light_sample (scene.rs:156-182); light probability = phi-weighted pick
-                    float wsum = 0.0f, wme = 0.0f;
-                    if (!(FEAT & FEAT_MLIGHT) || sc.n_lights == 1u) {
-                        // one light (every BASELINE config): phi(lambda) is Le * area, already evaluated
-                        // (emissive radiance cannot be a texture, so Le does not depend on uv)
-                        float sum = 0.0f;
-                        float area = sc.lights[0].area_sum;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += Le[i] * area;
-                        wsum = wme = sum / 4.0f;
-                    } else
-                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                        DevLight lt = sc.lights[li];
-                        const DevMaterial* lm = sc.materials + lt.material;
-                        float ph[4];
-                        DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                        float inten = lm->intensity;
-                        float sum = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += (ph[i] * inten) * lt.area_sum;
-                        float wt = sum / 4.0f;
-                        wsum += wt;
-                        if (li == sf.light) wme = wt;
-                    }
-                    float probability = wsum == 0.0f ? 0.0f : wme / wsum;
-                    f3 dv = prev_pos - sf.p;
-                    float distance = length(dv);
-                    f3 wo_l = -normalize(dv);
-                    float pdf_dir = sf.light_pdf_area * (distance * distance) / fabsf(dot(sf.ng, wo_l));
-                    w = balance_heuristic(p_pdf, probability * pdf_dir);
-                }
-                if (w != 0.0f || prm.strategy != 1u) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * ((pf[i] * Le[i]) * tf)) * w;
-                }
-            } else if (prm.strategy != 1u || prev_spec) {
-                // The reference adds T * (f * 0 / pdf) * w even when the next vertex is not a light
-                // (pt_renderer.rs:43, mis_renderer.rs:163-180 with pdf_light = 0).  That is +0 unless the sample's
-                // pdf or throughput is inf/NaN (rough transmission at grazing half vectors), in which case it poisons
-                // the sample with NaN exactly like the CPU path; keep that behaviour bit for bit.
-                float w = (prm.strategy == 2u && !prev_spec) ? balance_heuristic(p_pdf, 0.0f) : 1.0f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * ((pf[i] * 0.0f) * tf)) * w;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) T[i] = T[i] * (pf[i] * tf);
-            // apply_russian_roulette (:76-92)
-            float p = fmaxf(fmaxf(fmaxf(fmaxf(-INFINITY, T[0]), T[1]), T[2]), T[3]);
-            if (!(p >= 1.0f)) {
-                float ur = get_1d(smp, sctx);
-                if (ur < p) {
-                    if (p != 0.0f) {
-                        // four divisions, not one reciprocal: T_max / p must be exactly 1 so that the next vertex skips its roulette
-                        // draw like the reference does (x * (1/x) can be 0.99999994, and a draw more shifts every later dimension)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) T[i] = T[i] / p;
-                    }
-                } else end_path = true;
-            }
-        }
-        if (!end_path) {
-            depth += 1;                                                       // for _ in 1..=max_depth (:197)
-            if (depth > prm.max_depth || emissive) end_path = true;           // as_bsdf_material() == None (:199-202)
-        }
-        if (!end_path) {
-            if (STATS) { st.bounces++; tsa = __builtin_amdgcn_s_memtime(); }
-            Frame fr = shading_frame(sf.ns, sf.tangent);
-            f3 wo_r = -rd;                                                    // Intersection.wo
-            f3 wo = to_local(fr, wo_r);
-            f3 ng_t = normalize(to_local(fr, sf.ng));                         // Transform * Normal renormalises
-            // base_renderer.rs:212-213 draws uc then uv for every material.  A draw whose value the material
-            // never reads only has to advance the sampler's dimension (Lambert ignores uc, lambert_material.rs:44;
-            // the smooth dielectric ignores uv, dielectric.rs:179-180): the Sobol digit loop is ~30 % of this
-            // kernel's VALU time, so unused values are not computed.
-            const bool is_diel = (FEAT & FEAT_DIEL) && (mtype == MT_GLASS || mtype == MT_PLASTIC);
-            float uc = 0.0f;
-            f2 uv = f2{0.0f, 0.0f};
-            float d_alpha = mat->roughness;                                   // FloatParameter::sample(uv) (glass_material.rs:116, plastic_material.rs:104)
-            if ((FEAT & FEAT_TEX) && (FEAT & FEAT_ROUGH) && is_diel && mat->roughness_tex != 0xffffffffu) { float t3[3]; bilinear_rgb(sc, mat->roughness_tex, sf.uv, t3); d_alpha = t3[0]; }
-            const bool rough_diel = (FEAT & FEAT_ROUGH) && is_diel && d_alpha >= 1e-3f;            // !effectively_smooth (dielectric.rs:25-27)
-            if (is_diel) {
-                uc = get_1d(smp, sctx);
-                // Plastic indexes a *textured* colour with the random uv (plastic_material.rs:123-126, Q15)
-                if (rough_diel || (mtype == MT_PLASTIC && mat->color.kind == SPK_TEXTURE)) uv = get_2d(smp, sctx); else smp.dimension += 2;
-            }
-            else if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) { uc = get_1d(smp, sctx); uv = get_2d(smp, sctx); }
-            else { smp.dimension += 1; uv = get_2d(smp, sctx); }
-            // normal map frame (identity without a normal texture)
-            Frame nf;
-            if ((FEAT & FEAT_TEX) && mat->normal_tex != 0xffffffffu) {
-                float rgb[3];
-                bilinear_rgb(sc, mat->normal_tex, sf.uv, rgb);                // normal_texture.rs:39-66
-                float nx = rgb[0] * 2.0f - 1.0f, ny = rgb[1] * 2.0f - 1.0f, nz = rgb[2] * 2.0f - 1.0f;
-                if (mat->normal_flip_y) ny = -ny;
-                float len = sqrtf(nx * nx + ny * ny + nz * nz);
-                f3 nm = mk3(0, 0, 1);
-                if (len > 0.0f) nm = normalize(normalize(mk3(nx / len, ny / len, nz / len)));
-                nf = normal_map_frame(nm);
-            } else {
-                nf.t = mk3(1, 0, 0); nf.b = mk3(0, 1, 0); nf.n = mk3(0, 0, 1);
-            }
-            f3 wo_nm = to_local(nf, wo);
-            bool sampled = false, specular = false;
-            f3 wi_sh = mk3(0, 0, 1);
-            float s_f[4] = {0, 0, 0, 0}, s_pdf = 0.0f;
-            float geo_wo = dot(ng_t, wo);
-
-            // state the light connection needs to evaluate the BSDF again (BsdfSurfaceMaterial::{evaluate,pdf})
-            uint32_t nee_kind = 0;            // 0 none, 1 Lambert, 2 clearcoat, 3 rough dielectric
-            float d_er[4] = {1, 1, 1, 1};     // rough dielectric: relative eta per wavelength, flags
-            bool d_thin = false, d_plastic = false;
-            float albedo[4] = {0, 0, 0, 0};   // Lambert albedo / clearcoat base colour
-            float cc_tint[4] = {1, 1, 1, 1};
-            float cc_fc = 0.0f, cc_alpha_c = 0.0f, cc_alpha_b = 0.0f, cc_r0c = 0.0f, cc_r0d = 0.0f, cc_metallic = 0.0f, cc_thick = 0.0f;
-
-            if (mtype == MT_LAMBERT) {
-                // LambertMaterial::sample (lambert_material.rs:42-97) + NormalizedLambertBsdf (lambert.rs:38-75)
-                nee_kind = 1;
-                DevSpectrum cs = load_spectrum(&mat->color);
-                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
-                if (wo_nm.z != 0.0f) {
-                    float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                    float sn_th, cs_th; sincosf(th, &sn_th, &cs_th);                 // one range reduction for both (same values as sinf / cosf)
-                    f3 wi = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
-                    if (wo_nm.z < 0.0f) wi.z = -wi.z;
-                    if (wi.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi.z)) {
-                        f3 w = to_world(nf, wi);
-                        float gwi = dot(ng_t, w);
-                        if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) {
-                            sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) / PI_F;   // sampled f and pdf stay IEEE: for albedo 1 their ratio must round like the reference's (the `p >= 1` roulette gate)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = albedo[i] * fabsf(wi.z) / PI_F;
-                        }
-                    }
-                }
-            } else if (is_diel) {
-                // GlassMaterial/PlasticMaterial::sample -> DielectricBsdf::sample_specular (dielectric.rs:380-466)
-                float eta[4];
-                DevSpectrum es = load_spectrum(&mat->eta);
-                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, es, wl, sf.uv, eta, st);
-                bool eta_const = (eta[1] == eta[0]) && (eta[2] == eta[0]) && (eta[3] == eta[0]);
-                if (eta[0] == 0.0f) { eta[0] = eta[1] = eta[2] = eta[3] = 1.0f; eta_const = true; }   // DielectricBsdf::new :144-148
-                bool entering = geo_wo > 0.0f;
-                bool thin = mat->thin != 0;
-                if (rough_diel) {
-                    // DielectricBsdf::sample_microfacet (dielectric.rs:217-365), alpha = roughness (glass_material.rs:120-126)
-                    nee_kind = 3; d_thin = thin; d_plastic = mtype == MT_PLASTIC;
-                    const float alpha = d_alpha;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) d_er[i] = (thin || entering) ? eta[i] : sdiv(1.0f, eta[i]);
-                    if (wo_nm.z != 0.0f) {
-                        f3 wm = ggx_sample_wm(alpha, alpha, wo_nm, uv);
-                        float wodm = dot(wo_nm, wm);
-                        float fr4[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) fr4[i] = fresnel_dielectric1(fabsf(wodm), d_er[i]);
-                        float favg = (((0.0f + fr4[0]) + fr4[1]) + fr4[2] + fr4[3]) / 4.0f;
-                        float pr = favg, pt = 1.0f - favg;
-                        if (thin) { float r = favg, t = 1.0f - r, r2 = r * r; pr = r2 > 1.0f ? 1.0f : r + (t * t * r) / (1.0f - r2); pt = t; }
-                        f3 wi = mk3(0, 0, 1);
-                        if (uc < pr / (pr + pt)) {                                // sample_microfacet_reflection :284-314
-                            f3 w = wm * (2.0f * wodm) - wo_nm;
-                            float cd = fabsf(wodm);
-                            if (wo_nm.z * w.z > 0.0f && !(cd < 1e-6f)) {
-                                sampled = true; wi = w;
-                                s_pdf = ggx_Dw(alpha, alpha, wo_nm, wm) / (4.0f * cd) * (pr / (pr + pt));
-                                float dg = ggx_D(alpha, alpha, wm) * ggx_G(alpha, alpha, wo_nm, w);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) s_f[i] = fr4[i] * dg * fabsf(w.z) / (4.0f * fabsf(wo_nm.z));   // extra |cos wi| (Q8)
-                            }
-                        } else if (thin) {                                        // sample_specular_transmission_thin_surface :346-365
-                            sampled = true; wi = mk3(-wo_nm.x, -wo_nm.y, -wo_nm.z); s_pdf = pt / (pr + pt);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = 1.0f - fr4[i];
-                        } else {                                                  // sample_microfacet_transmission :316-344
-                            if (!eta_const) wl.term = true;
-                            const float etap = d_er[0];
-                            f3 wmr = entering ? wm : -wm;
-                            f3 w;
-                            if (refract(wo_nm, wmr, etap, w) && !(wo_nm.z * w.z > 0.0f) && fabsf(w.z) != 0.0f) {
-                                float sden = dot(w, wm) + wodm / etap;
-                                float denom = sden * sden;
-                                float dwm = fabsf(dot(w, wm)) / denom;
-                                sampled = true; wi = w;
-                                s_pdf = ggx_Dw(alpha, alpha, wo_nm, wm) * dwm * (pt / (pr + pt));
-                                float dg = ggx_D(alpha, alpha, wm) * ggx_G(alpha, alpha, wo_nm, w);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    s_f[i] = sdiv((1.0f - fr4[i]) * dg * fabsf(dot(w, wm)) * fabsf(wodm), denom * fabsf(wo_nm.z) * etap * etap);   // spectrum / f32: x/0 -> 0
-                            }
-                        }
-                        if (sampled) {
-                            if (d_plastic && dot(wi, wo_nm) < 0.0f) {
-                                float col[4];
-                                DevSpectrum cs = load_spectrum(&mat->color);
-                                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, uv, col, st);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) s_f[i] = s_f[i] * col[i];
-                            }
-                            wi_sh = to_world(nf, wi);
-                        }
-                    }
-                } else
-                if (wo_nm.z != 0.0f) {
-                    float er[4], fr4[4], favg;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) er[i] = (thin || entering) ? eta[i] : sdiv(1.0f, eta[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fr4[i] = fresnel_dielectric1(fabsf(wo_nm.z), er[i]);
-                    favg = (((0.0f + fr4[0]) + fr4[1]) + fr4[2] + fr4[3]) / 4.0f;
-                    float pr, pt;
-                    if (thin) {                                                   // calculate_thin_surface_coefficients :367-378
-                        float r = favg, t = 1.0f - r, r2 = r * r;
-                        pr = r2 > 1.0f ? 1.0f : r + (t * t * r) / (1.0f - r2);
-                        pt = t;
-                    } else { pr = favg; pt = 1.0f - pr; }
-                    f3 wi = mk3(0, 0, 1);
-                    if (uc < pr / (pr + pt)) {
-                        if (!(fabsf(wo_nm.z) < 1e-6f)) {
-                            sampled = true; specular = true; wi = mk3(-wo_nm.x, -wo_nm.y, wo_nm.z); s_pdf = pr / (pr + pt);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = fr4[i];
-                        }
-                    } else if (thin) {
-                        wi = mk3(-wo_nm.x, -wo_nm.y, -wo_nm.z);
-                        if (wi.z != 0.0f) {
-                            sampled = true; specular = true; s_pdf = pt / (pr + pt);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = 1.0f - fr4[i];
-                        }
-                    } else {
-                        if (!eta_const) wl.term = true;                           // terminate_secondary :446-448
-                        f3 n = entering ? mk3(0, 0, 1) : mk3(0, 0, -1);
-                        f3 wt;
-                        if (refract(wo_nm, n, er[0], wt) && wt.z != 0.0f) {
-                            sampled = true; specular = true; wi = wt; s_pdf = pt / (pr + pt);
-                            float e2 = er[0] * er[0];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = sdiv(1.0f - fr4[i], e2);
-                        }
-                    }
-                    if (sampled) {
-                        if (mtype == MT_PLASTIC && dot(wi, wo_nm) < 0.0f) {          // plastic_material.rs:123-126 (random uv, Q15)
-                            float col[4];
-                            DevSpectrum cs = load_spectrum(&mat->color);
-                            eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, uv, col, st);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = s_f[i] * col[i];
-                        }
-                        wi_sh = to_world(nf, wi);
-                    }
-                }
-                // failed dielectric samples are "Diffuse" (non-specular): the reference then runs NEE with
-                // f == 0 and ends the path; nothing observable happens, so it is skipped here.
-            }
-            else if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) {
-                // SimpleClearcoatPbrMaterial::sample (simple_pbr_clearcoat_material.rs:137-260)
-                nee_kind = 2;
-                DevSpectrum cs = load_spectrum(&mat->color);
-                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
-                DevSpectrum ts = load_spectrum(&mat->cc_tint);
-                eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ts, wl, sf.uv, cc_tint, st);
-                float metallic = mat->metallic; float thick = mat->cc_thickness;
-                float rough_b = mat->roughness;
-                if (FEAT & FEAT_TEX) {                                          // FloatParameter::Texture (parameter.rs:65-72)
-                    float t3[3];
-                    if (mat->metallic_tex != 0xffffffffu) { bilinear_rgb(sc, mat->metallic_tex, sf.uv, t3); metallic = t3[0]; }
-                    if (mat->roughness_tex != 0xffffffffu) { bilinear_rgb(sc, mat->roughness_tex, sf.uv, t3); rough_b = t3[0]; }
-                    if (mat->cc_thickness_tex != 0xffffffffu) { bilinear_rgb(sc, mat->cc_thickness_tex, sf.uv, t3); thick = t3[0]; }
-                }
-                cc_metallic = metallic; cc_thick = thick;
-                cc_alpha_c = mat->cc_roughness * mat->cc_roughness;                 // roughness_to_alpha :76-78
-                cc_alpha_b = rough_b * rough_b;
-                { float r = (mat->cc_ior - 1.0f) / (mat->cc_ior + 1.0f); cc_r0c = r * r; }   // compute_dielectric_r0 :81-84
-                { float r = (mat->ior - 1.0f) / (mat->ior + 1.0f); cc_r0d = r * r; }
-                // coat weight: 64-sample Monte Carlo of the coat's directional albedo, ONE stream per path vertex.
-                // The reference re-draws it from the thread RNG in sample(), evaluate() and pdf() (:190-192,318-320,416-418);
-                // sharing one estimate per vertex keeps every marginal identical and is 3x cheaper.
-                uint64_t mc_key = mix_bits(((uint64_t)smp.morton << 32) | (uint64_t)smp.dimension) ^ 0xD1B54A32D192ED03ull;
-                if (thick > 0.0f) cc_fc = coat_directional_albedo(cc_alpha_c, cc_r0c, wo_nm, mc_key);
-                bool base = true;
-                float ucb = uc;
-                if (thick > 0.0f) {
-                    if (uc < cc_fc) {
-                        base = false;
-                        GsSample g = gs_sample_R(cc_alpha_c, wo_nm, uv);
-                        if (g.ok) {
-                            sampled = true; specular = g.specular; wi_sh = to_world(nf, g.wi); s_pdf = g.pdf * cc_fc;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = (cc_r0c + (1.0f - cc_r0c) * g.p5) * g.dg;
-                        }
-                    } else ucb = (uc - cc_fc) / (1.0f - cc_fc);
-                }
-                if (base) {
-                    // sample_base_material (:336-383): metallic / dielectric(+Lambert) / mixed
-                    bool use_metal = metallic >= 1.0f || (metallic > 0.0f && ucb <= metallic);
-                    float ucd = (metallic > 0.0f && metallic < 1.0f) ? (ucb - metallic) / (1.0f - metallic) : ucb;
-                    f3 wi = mk3(0, 0, 1); bool okb = false; float fb[4] = {0, 0, 0, 0}, pb = 0.0f; bool specb = false;
-                    if (use_metal) {
-                        GsSample g = gs_sample_R(cc_alpha_b, wo_nm, uv);
-                        if (g.ok) {
-                            okb = true; wi = g.wi; pb = g.pdf; specb = g.specular;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) fb[i] = (albedo[i] + (1.0f - albedo[i]) * g.p5) * g.dg;
-                        }
-                    } else {
-                        float frd = cc_r0d + (1.0f - cc_r0d) * schlick_p5(fabsf(wo_nm.z));
-                        if (ucd < frd) {
-                            GsSample g = gs_sample_R(cc_alpha_b, wo_nm, uv);
-                            if (g.ok) {
-                                okb = true; wi = g.wi; pb = g.pdf * frd; specb = g.specular;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) fb[i] = (cc_r0d + (1.0f - cc_r0d) * g.p5) * g.dg;
-                            }
-                        } else if (wo_nm.z != 0.0f) {
-                            float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                            float sn_th, cs_th; sincosf(th, &sn_th, &cs_th);
-                            f3 w = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
-                            if (wo_nm.z < 0.0f) w.z = -w.z;
-                            if (w.z != 0.0f && sgn1(wo_nm.z) == sgn1(w.z)) {
-                                okb = true; wi = w; pb = (fabsf(w.z) / PI_F) * (1.0f - frd);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) fb[i] = (albedo[i] * fabsf(w.z) / PI_F) * (1.0f - frd);
-                            }
-                        }
-                    }
-                    if (okb) {
-                        sampled = true; specular = specb; wi_sh = to_world(nf, wi);
-                        if (thick > 0.0f) {
-                            s_pdf = pb * (1.0f - cc_fc);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                s_f[i] = fb[i] * (cc_attenuation1(cc_tint[i], thick, wo_nm.z) * cc_attenuation1(cc_tint[i], thick, wi_sh.z));   // Q14
-                        } else {
-                            s_pdf = pb;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_f[i] = fb[i];
-                        }
-                    }
-                }
-            }
-
-            else if ((FEAT & FEAT_METAL) && mtype == MT_METAL) {
-                // MetalMaterial::sample -> ConductorBsdf::sample (metal_material.rs:96-148, conductor.rs:257-329);
-                // eta lives in albedo[], k in cc_tint[] for the light connection below
-                nee_kind = 4;
-                DevSpectrum es = load_spectrum(&mat->eta), ks = load_spectrum(&mat->cc_tint);
-                eval_spectrum<STATS, false>(sc, es, wl, sf.uv, albedo, st);
-                eval_spectrum<STATS, false>(sc, ks, wl, sf.uv, cc_tint, st);
-                float rough_m = mat->roughness;
-                if ((FEAT & FEAT_TEX) && mat->roughness_tex != 0xffffffffu) { float t3[3]; bilinear_rgb(sc, mat->roughness_tex, sf.uv, t3); rough_m = t3[0]; }
-                const float alpha = rough_m * rough_m;                          // roughness_to_alpha :69-71
-                cc_alpha_b = alpha;                                             // kept for the light connection
-                if (wo_nm.z != 0.0f) {
-                    f3 wi = mk3(0, 0, 1); bool okm = false;
-                    if (alpha < 1e-3f) {                                        // sample_specular :276-298
-                        wi = mk3(-wo_nm.x, -wo_nm.y, wo_nm.z);
-                        okm = true; specular = true; s_pdf = 1.0f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) s_f[i] = fresnel_complex1(fabsf(wi.z), albedo[i], cc_tint[i]);
-                    } else {                                                    // sample_microfacet_reflection :300-329
-                        f3 wm = ggx_sample_wm(alpha, alpha, wo_nm, uv);
-                        float wodm = dot(wo_nm, wm);
-                        wi = wm * (2.0f * wodm) - wo_nm;
-                        if (wo_nm.z * wi.z > 0.0f) {
-                            okm = true;
-                            float co = fabsf(wo_nm.z), ci = fabsf(wi.z);
-                            if (co != 0.0f && ci != 0.0f) {                         // evaluate_torrance_sparrow :331-354
-                                const float dd = ggx_D(alpha, alpha, wm), gg = ggx_G(alpha, alpha, wo_nm, wi);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) s_f[i] = fresnel_complex1(fabsf(wodm), albedo[i], cc_tint[i]) * dd * gg / (4.0f * co);
-                            }
-                            // pdf_microfacet recomputes the half vector from (wo, wi) (:414-439)
-                            f3 h = wo_nm + wi;
-                            s_pdf = 0.0f;
-                            if (dot(h, h) != 0.0f) {
-                                f3 hm = normalize(h);
-                                float jac = 4.0f * fabsf(dot(wo_nm, hm));
-                                if (jac != 0.0f) s_pdf = ggx_Dw(alpha, alpha, wo_nm, hm) / jac;
-                            }
-                        }
-                    }
-                    if (okm) {
-                        f3 w = to_world(nf, wi);
-                        float gwi = dot(ng_t, w);
-                        if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) { sampled = true; wi_sh = w; }
-                        else specular = false;
-                    }
-                }
-            }
-
-            // a specular sample skips the light connection (base_renderer.rs:218); failed samples are 'Diffuse' and do not
-            if (specular) nee_kind = 0;
-            if (STATS) tsb = __builtin_amdgcn_s_memtime();
-            // NEE runs for every non-specular sample *including failed ones* (samples.rs:63-71, base_renderer.rs:218)
-            if (nee_kind != 0u && prm.strategy != 0u) {
-                // light pick: LightSampler (light_sampler.rs:26-43,190-220)
-                // with one light any u picks it (light_sampler.rs:31-42): only the dimension advances
-                float ul = 0.0f;
-                if (!(FEAT & FEAT_MLIGHT) || sc.n_lights == 1u) smp.dimension += 1; else ul = get_1d(smp, sctx);
-                // phi-weighted light pick.  The picked light's radiance is evaluated ONCE and doubles as its
-                // phi weight (emissive radiance is never a texture, so it does not depend on uv).
-                uint32_t pick = 0; float wsum = 0.0f, wpick = 0.0f;
-                float lrad[4];
-                if (!(FEAT & FEAT_MLIGHT) || sc.n_lights == 1u) {
-                    const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
-                    DevSpectrum ls0 = load_spectrum(&lm0->color);
-                    eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
-                    float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
-                    wsum = wpick = sum / 4.0f;
-                } else {
-                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                        DevLight lt = sc.lights[li];
-                        const DevMaterial* lm = sc.materials + lt.material;
-                        float ph[4];
-                        DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                        float sum = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
-                        wsum += sum / 4.0f;
-                    }
-                    float cum = 0.0f; bool chosen = false;
-                    pick = sc.n_lights - 1;
-                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                        DevLight lt = sc.lights[li];
-                        const DevMaterial* lm = sc.materials + lt.material;
-                        float ph[4];
-                        DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                        float sum = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
-                        float wt = sum / 4.0f;
-                        cum += wt;
-                        if (!chosen && (ul < cum / wsum || li == sc.n_lights - 1)) {
-                            chosen = true; pick = li; wpick = wt;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) lrad[i] = ph[i];
-                        }
-                    }
-                }
-                if (sc.n_lights > 0 && wsum != 0.0f) {
-                    float lprob = wpick / wsum;
-                    float s1 = get_1d(smp, sctx);
-                    f2 luv = get_2d(smp, sctx);
-                    DevLight lt = sc.lights[pick];
-                    const DevMaterial* lm = sc.materials + lt.material;
-                    f3 dv, wi_r, ln = mk3(0, 0, 1);
-                    float pdf_a = 1.0f, pdf_dir = 0.0f;
-                    float dl_scale = 1.0f;                                      // delta lights: falloff
-                    float env_rad[4] = {0, 0, 0, 0};
-                    if ((FEAT & FEAT_ENV) && lt.kind == LK_ENV) {               // sample_infinite_light (environment_light.rs:317-340)
-                        env_sample(sc, luv, wi_r, pdf_dir);
-                        dv = wi_r;
-                        env_radiance(sc, wi_r, wl, env_rad);
-                    } else if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
-                        // Scene::calculate_light for PrimitiveDelta{Point,Directional}Light (scene.rs:114-139)
-                        if (lt.kind == LK_DIRECTIONAL) {                        // directional_light.rs:95-107
-                            dv = mk3(lt.pos[0], lt.pos[1], lt.pos[2]);
-                            wi_r = normalize(dv);
-                        } else {                                                // point_light.rs:83-93, spot_light.rs:99-122
-                            dv = mk3(lt.pos[0], lt.pos[1], lt.pos[2]) - sf.p;
-                            wi_r = normalize(dv);
-                            if (lt.kind == LK_SPOT) {
-                                float theta = lt.axis[0] * wi_r.x + lt.axis[1] * wi_r.y + lt.axis[2] * wi_r.z;
-                                float t = fminf(fmaxf((theta - lt.angle_outer) / (lt.angle_inner - lt.angle_outer), 0.0f), 1.0f);
-                                dl_scale = t * t * (3.0f - 2.0f * t);
-                            }
-                        }
-                    } else {
-                    // EmissiveTriangleMesh::sample_radiance (emissive_triangle_mesh.rs:176-308)
-                    // first k with s < cdf[k] (else 0, :185-191).  The cdf is non-decreasing, so that index is the
-                    // number of entries <= s: independent loads instead of a chain of dependent ones.
-                    uint32_t cnt = 0;
-                    for (uint32_t k = 0; k < lt.n_tris; ++k) cnt += (s1 < sc.light_tris[lt.first_tri + k].cdf) ? 0u : 1u;
-                    uint32_t tsel = cnt < lt.n_tris ? cnt : 0u;
-                    const float4* q = (const float4*)(sc.light_tris + lt.first_tri + tsel);
-                    float4 qa = q[0], qb = q[1], qc = q[2], qd = q[3];
-                    f3 p0 = mk3(qa.x, qa.y, qa.z), p1 = mk3(qa.w, qb.x, qb.y), p2 = mk3(qb.z, qb.w, qc.x);
-                    float b0, b1;
-                    if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
-                    float b2 = 1.0f - b0 - b1;
-                    f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
-                    ln = mk3(qc.z, qc.w, qd.x);                                  // normalize(normalize(cross(p1 - p0, p2 - p0))), precomputed
-                    pdf_a = 1.0f / lt.area_sum;
-                    dv = lp - sf.p;
-                    wi_r = normalize(dv);
-                    float distance = length(lp - sf.p);
-                    pdf_dir = pdf_a * (distance * distance) / fmaxf(fabsf(dot(ln, -wi_r)), 1e-8f);
-                    }
-                    // evaluate_area_light{,_with_mis} (common.rs:82-171)
-                    f3 wi_t = to_local(fr, wi_r);
-                    f3 wi_nm = to_local(nf, wi_t);
-                    float fl[4] = {0, 0, 0, 0}; float pdf_b = 0.0f;
-                    float gwi = dot(ng_t, wi_t);
-                    if ((FEAT & FEAT_ROUGH) && nee_kind == 3u) {                 // DielectricBsdf::{evaluate_microfacet,pdf_microfacet} (:468-645)
-                        const float alpha = d_alpha;
-                        const float es = d_er[0];
-                        float co = wo_nm.z, ci = wi_nm.z;
-                        bool refl = ci * co > 0.0f;
-                        float etap = !refl ? (co > 0.0f ? es : 1.0f / es) : 1.0f;
-                        f3 wm = wi_nm * etap + wo_nm;
-                        bool ok = !(ci == 0.0f || co == 0.0f || dot(wm, wm) == 0.0f);
-                        if (ok) {
-                            wm = normalize(wm);
-                            if (wm.z < 0.0f) wm = -wm;
-                            if (dot(wm, wi_nm) * ci < 0.0f || dot(wm, wo_nm) * co < 0.0f) ok = false;
-                        }
-                        if (ok) {
-                            float wodm = dot(wo_nm, wm), widm = dot(wi_nm, wm);
-                            float fr4[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) fr4[i] = fresnel_dielectric1(fabsf(wodm), d_er[i]);
-                            float pr = (((0.0f + fr4[0]) + fr4[1]) + fr4[2] + fr4[3]) / 4.0f, pt = 1.0f - pr;
-                            float dg = ggx_D(alpha, alpha, wm) * ggx_G(alpha, alpha, wo_nm, wi_nm);
-                            if (refl) {
-                                pdf_b = ggx_Dw(alpha, alpha, wo_nm, wm) / (4.0f * fabsf(wodm)) * pr / (pr + pt);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) fl[i] = fr4[i] * dg / (4.0f * fabsf(wo_nm.z));
-                            } else {
-                                float sden = widm + wodm / es;
-                                float denom = sden * sden;
-                                pdf_b = d_thin ? pt / (pr + pt) : ggx_Dw(alpha, alpha, wo_nm, wm) * (fabsf(widm) / denom) * pt / (pr + pt);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) fl[i] = sdiv((1.0f - fr4[i]) * dg * fabsf(widm) * fabsf(wodm), denom * fabsf(wo_nm.z) * es * es);
-                            }
-                        }
-                        if (d_plastic && dot(wi_nm, wo_nm) < 0.0f) {              // plastic_material.rs:169-172 (surface uv here)
-                            float col[4];
-                            DevSpectrum cs = load_spectrum(&mat->color);
-                            eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, col, st);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) fl[i] = fl[i] * col[i];
-                        }
-                    } else if ((FEAT & FEAT_METAL) && nee_kind == 4u) {          // MetalMaterial::{evaluate,pdf} (metal_material.rs:150-229)
-                        const float alpha = cc_alpha_b;
-                        if (sgn1(gwi) == sgn1(geo_wo) && !(alpha < 1e-3f) && fabsf(wo_nm.z) != 0.0f && fabsf(wi_nm.z) != 0.0f && wo_nm.z * wi_nm.z > 0.0f) {
-                            f3 h = wo_nm + wi_nm;
-                            if (dot(h, h) != 0.0f) {
-                                f3 wm = normalize(h);
-                                float wodm = dot(wo_nm, wm);
-                                const float dd = ggx_D(alpha, alpha, wm), gg = ggx_G(alpha, alpha, wo_nm, wi_nm);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) fl[i] = fresnel_complex1(fabsf(wodm), albedo[i], cc_tint[i]) * dd * gg / (4.0f * fabsf(wo_nm.z));
-                                float jac = 4.0f * fabsf(wodm);
-                                if (jac != 0.0f) pdf_b = ggx_Dw(alpha, alpha, wo_nm, wm) / jac;
-                            }
-                        }
-                    } else if (!(FEAT & FEAT_CC) || nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
-                        if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
-                            pdf_b = fabsf(wi_nm.z) * INV_PI_F;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) fl[i] = (albedo[i] * fabsf(wi_nm.z)) * INV_PI_F;
-                        }
-                    } else {                                                  // SimpleClearcoatPbrMaterial::{evaluate,pdf} (:261-433)
-                        float dgc, p5c, pdfc, dgb, p5b, pdfb;
-                        gs_eval_R(cc_alpha_c, wo_nm, wi_nm, dgc, p5c, pdfc);
-                        gs_eval_R(cc_alpha_b, wo_nm, wi_nm, dgb, p5b, pdfb);
-                        float metallic = cc_metallic;
-                        // Lambert lobe of the dielectric base (lambert.rs:77-120)
-                        float lam_f = 0.0f, lam_pdf = 0.0f;
-                        if (wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) { lam_f = fabsf(wi_nm.z) / PI_F; lam_pdf = lam_f; }
-                        float frd = cc_r0d + (1.0f - cc_r0d) * schlick_p5(fabsf(wo_nm.z));     // fresnel(wo).average(), scalar r0
-                        float pdf_met = pdfb, pdf_die = frd * pdfb + (1.0f - frd) * lam_pdf;
-                        float pdf_base = metallic >= 1.0f ? pdf_met : (metallic <= 0.0f ? pdf_die : pdf_met * metallic + pdf_die * (1.0f - metallic));
-                        float thick = cc_thick;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            float f_met = (albedo[i] + (1.0f - albedo[i]) * p5b) * dgb;
-                            float f_die = (cc_r0d + (1.0f - cc_r0d) * p5b) * dgb + (1.0f - frd) * (albedo[i] * lam_f);
-                            float f_base = metallic >= 1.0f ? f_met : (metallic <= 0.0f ? f_die : f_met * metallic + f_die * (1.0f - metallic));
-                            if (thick <= 0.0f) fl[i] = f_base;
-                            else {
-                                float att = cc_attenuation1(cc_tint[i], thick, wo_nm.z) * cc_attenuation1(cc_tint[i], thick, wi_nm.z);
-                                fl[i] = ((cc_r0c + (1.0f - cc_r0c) * p5c) * dgc) * cc_fc + f_base * att * (1.0f - cc_fc);
-                            }
-                        }
-                        pdf_b = thick <= 0.0f ? pdf_base : pdfc * cc_fc + pdf_base * (1.0f - cc_fc);
-                    }
-                    float dist2 = dot(dv, dv);
-                    do_shadow = true;
-                    if ((FEAT & FEAT_ENV) && lt.kind == LK_ENV) {               // evaluate_infinite_light{,_with_mis} (common.rs:174-241)
-                        float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
-                        sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = 3.402823466e+38f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sh_c[i] = (T[i] * sdiv(fl[i] * env_rad[i], pdf_dir * lprob)) * wgt;
-                    } else if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
-                        // evaluate_delta_{point,directional}_light (common.rs:23-79): no MIS weight
-                        if (lt.kind == LK_DIRECTIONAL) {
-                            sh_d = dv; sh_o = sf.p; sh_t = 3.402823466e+38f;      // the ray is not moved forward (:60-61)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) sh_c[i] = (T[i] * ((fl[i] * (lt.intensity * lrad[i])) / lprob)) * 1.0f;
-                        } else {
-                            sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                float inten = lt.intensity * lrad[i];
-                                if (lt.kind == LK_SPOT) inten = inten * dl_scale;
-                                sh_c[i] = (T[i] * ((fl[i] * inten) / (dist2 * lprob))) * 1.0f;
-                            }
-                        }
-                    } else {
-                    f3 ln_t = normalize(to_local(fr, ln));
-                    float g = fabsf(dot(ln_t, -wi_t)) / dist2;
-                    float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
-                    sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
-                    const float rden = 1.0f / (pdf_a * lprob);   // one division for the four wavelengths (<= 1 ulp from x / (pdf_a * lprob))
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        sh_c[i] = (T[i] * (((fl[i] * (lrad[i] * lm->intensity)) * g) * rden)) * wgt;
-                    }
-                }
-            }
-
-            if (!sampled) {
-                end_path = true;                                              // process_bsdf_sampling -> None (:102-104,240-253)
-            } else {
-                // spawn the next ray (:106-121)
-                f3 wi_r = to_world(fr, wi_sh);
-                float sg = dot(sf.ng, wi_r) < 0.0f ? -1.0f : 1.0f;
-                f3 org = sf.p + (sg * sf.ng) * RAY_EPS;
-                rd = wi_r; ro = org + rd * RAY_EPS;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pf[i] = s_f[i];
-                p_pdf = s_pdf; prev_spec = specular; prev_pos = sf.p; from_camera = false;
-            }
-        }
-    }
-    return end_path;
-}
-
-// ---- the same vertex in two halves (shade_vertex_a / shade_vertex_b below) for kernels with the clearcoat material: between the
-// halves the wave estimates the coat's directional albedo cooperatively.  Kernels without FEAT_CC use the single function above:
-// carrying the hand-over state across the re-convergence point costs registers (measured: -29 % on scene 3 when forced).
-// The two forms must be edited together.  Both are covered on every scene: the per-sample radiance probes run the all-features
-// kernel (the two-halves form), the frame comparisons the scene's own specialisation (single function unless it has a clearcoat). ----
-// What the first half of a vertex (surface, emission, throughput, Russian roulette, frames, BSDF draws) hands to the second half
-// (BSDF sample, light connection).  Between the two the wave estimates the clearcoat's directional albedo cooperatively.
+// One path vertex in two halves.  The closest-hit result of P.ro/P.rd arrives (got/hit):
+//   shade_vertex_head  accounts emission (with the strategy's weight), applies throughput + Russian roulette, builds the shading frames
+//                      and draws the BSDF's random numbers; returns true when the path ends here, else C.cont is set;
+//   shade_vertex_tail  samples the BSDF and the light: P.ro/P.rd hold the next ray, `sh` the light connection (it may be set even
+//                      when the path ends).
+// Kernels with the clearcoat material estimate the coat's directional albedo wave-cooperatively BETWEEN the halves (pt_kernel.hpp);
+// all other kernels call the two halves back to back inside one divergent region (shade_vertex below), which compiles to the code of
+// a single function: ShadeCtx never crosses a re-convergence point there.  One source for every kernel, probe included.
+// What the first half hands to the second half:
 struct ShadeCtx {
     Surface sf; const DevMaterial* mat; uint32_t mtype;
     Frame fr, nf; f3 wo, wo_nm, ng_t; float geo_wo, uc; f2 uv;
@@ -927,7 +235,7 @@ struct ShadeCtx {
 };
 
 template <bool STATS, uint32_t FEAT>
-PT_DEV bool shade_vertex_a(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, bool got, const Hit& hit, ShadowReq& sh,
+PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, bool got, const Hit& hit, ShadowReq& sh,
                            StatCounters& st, unsigned long long& tsa, ShadeCtx& C) {
     Sampler& smp = P.smp; Wl& wl = P.wl; float* T = P.T; float* L = P.L; f3& ro = P.ro; f3& rd = P.rd;
     bool& from_camera = P.from_camera; bool& prev_spec = P.prev_spec; float* pf = P.pf; float& p_pdf = P.p_pdf; f3& prev_pos = P.prev_pos;
@@ -1113,7 +421,7 @@ PT_DEV bool shade_vertex_a(Path& P, const DevScene& sc, const DevParams& prm, co
 }
 
 template <bool STATS, uint32_t FEAT>
-PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, ShadowReq& sh, StatCounters& st,
+PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, ShadowReq& sh, StatCounters& st,
                            unsigned long long& tsb, const ShadeCtx& C) {
     Sampler& smp = P.smp; Wl& wl = P.wl; float* T = P.T; float* L = P.L; f3& ro = P.ro; f3& rd = P.rd;
     bool& from_camera = P.from_camera; bool& prev_spec = P.prev_spec; float* pf = P.pf; float& p_pdf = P.p_pdf; f3& prev_pos = P.prev_pos;
@@ -1648,52 +956,54 @@ PT_DEV bool shade_vertex_b(Path& P, const DevScene& sc, const DevParams& prm, co
     return end_path;
 }
 
-struct PathOut { float* L; float* lam; float* pdf; };   // probe output (one path per lane)
+// Per-sample log (mi355pt_render_sample_log): when L != nullptr every finished path of the launch also writes its spectral radiance,
+// wavelengths and wavelength pdfs to slot ((tile_k * 64 + pixel in tile) * n_s + (sample index - s_base)).  A wave-uniform branch at
+// path end in the PRODUCTION kernel: the per-sample parity tests read what the benchmarked binary computed, in its own launch shape.
+struct PathOut { float* L; float* lam; float* pdf; uint32_t s_base, n_s; };
 
-// Sensor::add_sample (sensor.rs:41-78): fold the finished path into the lane's film sums (or the probe output)
-template <bool PROBE>
-PT_DEV void film_add(const Path& P, const DevScene& sc, const DevParams& prm, float& acc_r, float& acc_g, float& acc_b, const PathOut& pout, uint32_t qi) {
+PT_DEV void sample_log(const Path& P, const PathOut& pout, size_t slot) {
+    const float pdf0 = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
+    float4 l = make_float4(P.L[0], P.L[1], P.L[2], P.L[3]), w = make_float4(P.wl.lam[0], P.wl.lam[1], P.wl.lam[2], P.wl.lam[3]);
+    float4 q = P.wl.term ? make_float4(pdf0 / 4.0f, 0.0f, 0.0f, 0.0f) : make_float4(pdf0, pdf0, pdf0, pdf0);   // sampled_spectrum.rs:346-365
+    ((float4*)pout.L)[slot] = l; ((float4*)pout.lam)[slot] = w; ((float4*)pout.pdf)[slot] = q;
+}
+
+// Sensor::add_sample (sensor.rs:41-78): the RGB contribution of one finished path, added to the work item's LDS film tile
+PT_DEV void film_rgb(const Path& P, const DevScene& sc, const DevParams& prm, float& r_out, float& g_out, float& b_out) {
     const Wl& wl = P.wl; const float* L = P.L;
     const float pdf0 = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
-
-    if (PROBE) {
-        
+    float X = 0.0f, Y = 0.0f, Z = 0.0f;
+    const float4* cmf = (const float4*)sc.cmf;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pout.L[4 * qi + i] = L[i]; pout.lam[4 * qi + i] = wl.lam[i];
-            pout.pdf[4 * qi + i] = wl.term ? (i == 0 ? pdf0 / 4.0f : 0.0f) : pdf0;
+    for (int k = 0; k < 4; ++k) {
+        if (k == 0 || !wl.term) {
+            int idx = (int)floorf(wl.lam[k] - LAMBDA_MIN);
+            if (idx == 470) idx = 0;
+            // sensor.rs:52-66 divides by the wavelength pdf (1/470, or 1/1880 for a terminated sample) and by 4: the pdf is one of two
+            // constants, so its reciprocal is folded at compile time (<= 1 ulp from L / pdf)
+            const float inv_pdf = wl.term ? 1.0f / (pdf0 / 4.0f) : 1.0f / pdf0;
+            float c = (L[k] * inv_pdf) / 4.0f;
+            float4 m = cmf[idx];
+            X += c * m.x; Y += c * m.y; Z += c * m.z;
         }
-    } else {
-        float X = 0.0f, Y = 0.0f, Z = 0.0f;
-        const float4* cmf = (const float4*)sc.cmf;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k == 0 || !wl.term) {
-                int idx = (int)floorf(wl.lam[k] - LAMBDA_MIN);
-                if (idx == 470) idx = 0;
-                // sensor.rs:52-66 divides by the wavelength pdf (1/470, or 1/1880 for a terminated sample) and by 4: the pdf is one of two
-                // constants, so its reciprocal is folded at compile time (<= 1 ulp from L / pdf)
-                const float inv_pdf = wl.term ? 1.0f / (pdf0 / 4.0f) : 1.0f / pdf0;
-                float c = (L[k] * inv_pdf) / 4.0f;
-                float4 m = cmf[idx];
-                X += c * m.x; Y += c * m.y; Z += c * m.z;
-            }
-        }
-        const float* M = prm.xyz_to_rgb;   // row-major; glam Mat3*Vec3 = col0*x + col1*y + col2*z
-        float r = M[0] * X + M[1] * Y + M[2] * Z;
-        float g = M[3] * X + M[4] * Y + M[5] * Z;
-        float b = M[6] * X + M[7] * Y + M[8] * Z;
-        acc_r += r * prm.exposure; acc_g += g * prm.exposure; acc_b += b * prm.exposure;
     }
+    const float* M = prm.xyz_to_rgb;   // row-major; glam Mat3*Vec3 = col0*x + col1*y + col2*z
+    float r = M[0] * X + M[1] * Y + M[2] * Z;
+    float g = M[3] * X + M[4] * Y + M[5] * Z;
+    float b = M[6] * X + M[7] * Y + M[8] * Z;
+    r_out = 0.0f + r * prm.exposure; g_out = 0.0f + g * prm.exposure; b_out = 0.0f + b * prm.exposure;
 }
 
-// the RGB contribution of one finished path (the non-probe arm of film_add below), for the pooled loop's LDS film
-PT_DEV void film_rgb(const Path& P, const DevScene& sc, const DevParams& prm, float& r_out, float& g_out, float& b_out) {
-    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
-    PathOut none{nullptr, nullptr, nullptr};
-    film_add<false>(P, sc, prm, ar, ag, ab, none, 0u);
-    r_out = ar; g_out = ag; b_out = ab;
+// The vertex as ONE call, for the kernels without the clearcoat material (see ShadeCtx above)
+template <bool STATS, uint32_t FEAT>
+PT_DEV bool shade_vertex(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, bool got, const Hit& hit, ShadowReq& sh,
+                         StatCounters& st, unsigned long long& tsa, unsigned long long& tsb) {
+    static_assert((FEAT & FEAT_CC) == 0u, "clearcoat kernels run the cooperative albedo estimate between the halves");
+    ShadeCtx C;
+    C.cont = false; C.need_cc = false; C.cc_fc = 0.0f;
+    bool end_path = shade_vertex_head<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, C);
+    if (C.cont) end_path = shade_vertex_tail<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
+    return end_path;
 }
-
 
 }  // namespace pt

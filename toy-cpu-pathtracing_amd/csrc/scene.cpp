@@ -131,6 +131,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { *err = "no HIP device: the product path requires a gfx950 GPU"; return MI355PT_E_NO_DEVICE; }
     (void)hipGetDevice(&device);
+    std::memcpy(build_cam_pos, cam->position, sizeof(build_cam_pos));
 
     // world -> render = translate(-camera position)  (camera.rs:84-86, scene.rs:65-66)
     float w2r[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -cam->position[0], -cam->position[1], -cam->position[2], 1};

@@ -54,7 +54,8 @@ struct SceneImpl {
     std::vector<HostDeltaLight> delta_lights;   // creation order; after_instances = instances.size() at creation (light_sampler.rs:163-180)
     // ---- lowered ----
     bool built = false;
-    int device = -1;
+    int device = -1;              // the HIP device build() uploaded to: render calls must run with it current
+    float build_cam_pos[3] = {0, 0, 0};   // camera position baked into the render-space records (world -> render translation)
     DevScene dev{};
     std::vector<void*> allocs;
     uint32_t cmf_lut[3] = {0, 0, 0};

@@ -109,7 +109,8 @@ def _ptr(a, ty):
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
     "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_set_bvh_builder", "scene_build", "render", "render_accum_device", "film_resolve_device",
-    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "last_error", "version",
+    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log",
+    "last_error", "version",
 ]
 
 
@@ -297,6 +298,9 @@ class Product(Backend):
         lib.mi355pt_render_accum_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32,
                                                     C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         lib.mi355pt_film_resolve_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.mi355pt_sample_log_records.argtypes = [C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]
+        lib.mi355pt_render_sample_log.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32] + \
+            [C.POINTER(C.c_float)] * 3 + [C.c_size_t, C.POINTER(C.c_float)]
 
     def version(self):
         return self.lib.mi355pt_version().decode()
@@ -318,6 +322,20 @@ class Product(Backend):
         self.check(self.lib.mi355pt_render_accum_device(scene.h, C.byref(cam), C.byref(params), s_begin, s_end, C.c_void_p(d_accum_ptr),
                                                         C.c_void_p(stream or 0), C.byref(stats) if stats is not None else None),
                    "render_accum_device")
+
+    def render_sample_log(self, scene, cam, params, s_begin, s_end, want_accum=False):
+        """mi355pt_render_sample_log: every finished path of the production launch(es) for [s_begin, s_end) of the shard in `params`.
+        Returns L, lambda, pdf as (tiles_of_shard, 64, s_end - s_begin, 4) arrays (pixel (y & 7) * 8 + (x & 7) inside its 8x8 tile;
+        tile k of the shard is frame tile shard_index + k * shard_count) and, on request, the (H, W, 3) linear film sums."""
+        n = C.c_size_t()
+        self.check(self.lib.mi355pt_sample_log_records(C.byref(cam), C.byref(params), s_begin, s_end, C.byref(n)), "sample_log_records")
+        ns = s_end - s_begin
+        shape = (n.value // (64 * ns), 64, ns, 4)
+        L = np.zeros(shape, np.float32); lam = np.zeros(shape, np.float32); pdf = np.zeros(shape, np.float32)
+        acc = np.zeros((cam.height, cam.width, 3), np.float32) if want_accum else None
+        self.check(self.lib.mi355pt_render_sample_log(scene.h, C.byref(cam), C.byref(params), s_begin, s_end, _ptr(L, C.c_float),
+                                                      _ptr(lam, C.c_float), _ptr(pdf, C.c_float), n.value, _ptr(acc, C.c_float)), "render_sample_log")
+        return (L, lam, pdf, acc) if want_accum else (L, lam, pdf)
 
     def film_resolve_device(self, d_accum_ptr, n_pixels, spp, d_out_ptr, stream=None):
         self.check(self.lib.mi355pt_film_resolve_device(C.c_void_p(d_accum_ptr), n_pixels, spp, C.c_void_p(d_out_ptr),
