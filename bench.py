@@ -9,7 +9,9 @@ ranges of S sample indices per step instead, e.g. progressive refinement; jobs a
 Inputs (BVH, triangles, materials, LUTs, tables, textures) are resident in HBM before the timed region; the film
 accumulators stay in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's 8x8 pixel tiles are dealt round-robin to
+N > 1 (one rank per GPU; either launched by torch.distributed.run, or plainly as `python bench.py --gpus N`, in which
+case this process starts torch.distributed.run itself as a CHILD before touching any GPU and relays rank 0's JSON
+line): the frame's 8x8 pixel tiles are dealt round-robin to
 the ranks (scene replicated); each rank renders its own tiles into its own linear film, with no data-path collective,
 and when a frame's last sample index is done the films are summed onto rank 0 with ONE RCCL reduce over xGMI, inside
 the timed region (strong scaling: the frame is fixed).
@@ -28,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# VALU issue peak (same guide): 256 CUs x 4 SIMD-32 per CU, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz max clock
+PEAK_VALU_GINSTR = 256 * 4 * 2.4 / 2.0   # = 1228.8 G wave-level VALU instructions per second
 
 
 def algorithmic_bytes_per_sample(st, spp_total):
@@ -57,15 +61,26 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline duration")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched plainly: start one rank per GPU as children of this process (which has not touched a GPU and never will),
+        # relay their output (rank 0 prints the JSON line) and exit with their code
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    import torch
+    import torch.distributed as dist
+
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # MI355PT_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the film
@@ -146,27 +161,44 @@ def main():
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         launch_samples = samples_per_step / world
         achieved = bps * launch_samples / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,
-                    "kernel": "pt_kernel<STATS=false,PROBE=false,FEAT=scene feature mask>", "kernel_ms_avg": round(avg_ms, 3),
-                    "algorithmic_bytes_per_sample": round(bps, 1),
-                    "per_sample": {k: round(sd[k] / max(sd["samples"], 1), 3) for k in
-                                   ("closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow",
-                                    "closest_hits", "bounces", "spectrum_evals", "textured_lookups")}}
+        algo = {"bytes_per_sample": round(bps, 1), "GBps": round(achieved, 2), "frac_of_hbm_peak": round(achieved / PEAK_HBM_GBPS, 5),
+                "bytes_per_launch": round(bps * launch_samples),
+                "per_sample": {k: round(sd[k] / max(sd["samples"], 1), 3) for k in
+                               ("closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow",
+                                "closest_hits", "bounces", "spectrum_evals", "textured_lookups")}}
+        # What bounds the kernel is VALU issue on a cache-resident working set, not HBM: `achieved` / `peak` / `frac` are
+        # wave-level VALU instructions per second against the chip's issue peak.  The instruction count per sample comes from the
+        # committed SQ PMC pass of THIS workload on THIS library build (tools/profile_bench.sh -> profiles/pmc_valu.json; counters
+        # cannot be read from inside the process), the duration is measured live.  The SURVEY 8(d) algorithmic-bytes figure stays as
+        # `algorithmic` (frac_of_hbm_peak is what round 1 reported as `frac`), the PMC HBM traffic as `traffic` / `hbm_*`.
+        wl = {"scene": args.scene, "width": W, "height": H, "spp": spp_job, "spp_per_step": sps,
+              "strategy": args.strategy, "sampler": args.sampler, "n_gpus": world}
+        roofline = {"bound": "valu", "achieved": None, "peak": round(PEAK_VALU_GINSTR, 1), "unit": "Gwave-instr/s", "frac": None, "traffic": None,
+                    "kernel": "pt_kernel<STATS=false,FEAT=scene feature mask,MODE>", "kernel_ms_avg": round(avg_ms, 3),
+                    "valu": None, "algorithmic": algo}
+        pv = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if os.path.exists(pv):
+            try:
+                vj = json.load(open(pv))
+                if vj.get("workload") == wl and vj.get("library") == prod.version():
+                    ips = vj["SQ_INSTS_VALU_per_launch"] / vj["samples_per_launch"]
+                    ach = ips * launch_samples / (avg_ms * 1e-3) / 1e9
+                    lane_use = vj["SQ_THREAD_CYCLES_VALU_per_launch"] / (64.0 * vj["SQ_INSTS_VALU_per_launch"])
+                    roofline.update({"achieved": round(ach, 1), "frac": round(ach / PEAK_VALU_GINSTR, 4)})
+                    roofline["valu"] = {"wave_instr_per_sample": round(ips, 1), "issue_frac": round(ach / PEAK_VALU_GINSTR, 4),
+                                        "lane_use": round(lane_use, 4), "useful_lane_frac": round(ach / PEAK_VALU_GINSTR * lane_use, 4),
+                                        "source": "profiles/pmc_valu.json"}
+            except Exception:
+                pass
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh: separate
                 # FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied); only valid for
-                # the workload it was collected on
+                # the workload and library build it was collected on
                 pj = json.load(open(pmc))
-                wl = {"scene": args.scene, "width": W, "height": H, "spp": spp_job, "spp_per_step": sps,
-                      "strategy": args.strategy, "sampler": args.sampler, "n_gpus": world}
-                if pj.get("workload") == wl:
+                if pj.get("workload") == wl and pj.get("library") == prod.version():
                     roofline["traffic"] = pj.get("hbm_bytes_per_launch")
-                    roofline["algorithmic_bytes_per_launch"] = round(bps * launch_samples)
-                    # the working set is cache-resident, so three figures are reported — algorithmic bytes/s (= achieved),
-                    # HBM/fabric bytes/s from the PMC passes, and the L2 (TCC) request rate (128-B lines on gfx950)
                     roofline["hbm_GBps"] = round(roofline["traffic"] / (avg_ms * 1e-3) / 1e9, 1)
                     roofline["hbm_frac"] = round(roofline["hbm_GBps"] / PEAK_HBM_GBPS, 5)
                     if "TCC_HIT_sum_per_launch" in pj:

@@ -120,6 +120,10 @@ typedef struct mi355pt_params {
     uint32_t collect_stats;            /* run the instrumented kernel variant and fill mi355pt_stats: 1 = with the reference's
                                         * traversal order (the canonical per-sample node/triangle counts of SURVEY.md 8d),
                                         * 2 = with the production traversal (cooperative, slightly more nodes; lane-use diagnostics) */
+    float rr_gate_slack;               /* diagnostic, 0 = the reference: apply_russian_roulette skips the roulette when
+                                        * max(T) >= 1 (base_renderer.rs:76-92); with a slack s the gate is max(T) >= 1 - s.
+                                        * Used by the parity tests to show that GPU / oracle path flips on solid constant-eta
+                                        * dielectrics come from that gate sitting on T = F * (1 / pdf) = 1 +- 1 ulp */
 } mi355pt_params;
 
 typedef struct mi355pt_stats {

@@ -36,6 +36,7 @@ struct Camera {     // camera.rs:14-92
 
 struct RenderParams {
     uint32_t width = 0, height = 0, spp = 1, seed = 0, max_depth = 16;
+    float rr_gate = 1.0f;   // roulette is skipped when max(T) >= rr_gate; 1 = the reference (mi355pt_params.rr_gate_slack, diagnostic)
     uint32_t strategy = STRAT_MIS, sampler = 1;
     float exposure = 1.0f;
 };
@@ -224,7 +225,11 @@ struct PathTracer {
     }
 
     // one camera path; returns L and the (possibly terminated) wavelengths
-    SS trace(uint32_t px, uint32_t py, uint32_t sample_index, Wavelengths* wl_out, Counters* c) const {
+    // `flags` (diagnostic, optional): bit 0 = some Russian-roulette gate of this path sat on a knife edge, max(T) within 2 ulp of 1.
+    // The gate `p >= 1` (base_renderer.rs:76-92) decides whether a random number is drawn at all; a reflection off a constant-eta
+    // dielectric has f = F and pdf = F / (F + (1 - F)), so T = F * (1 / pdf) lands on 1 or 1 - ulp depending on the last bit of F.
+    // An implementation whose cos(theta) differs in the last ulp takes the other branch, and every later Sobol dimension shifts.
+    SS trace(uint32_t px, uint32_t py, uint32_t sample_index, Wavelengths* wl_out, Counters* c, uint32_t* flags = nullptr) const {
         Sampler smp = Sampler::create((int)prm.sampler, prm.spp, prm.width, prm.height, prm.seed);
         smp.start_pixel_sample(px, py, sample_index, prm.width);
         SS T = SS::one(), L = SS::zero();
@@ -325,7 +330,8 @@ struct PathTracer {
             hit = nh;
             // apply_russian_roulette (base_renderer.rs:76-92)
             float p = T.max_value();
-            if (!(p >= 1.0f)) {
+            if (flags && std::fabs(p - 1.0f) <= 2.4e-7f) *flags |= 1u;
+            if (!(p >= prm.rr_gate)) {
                 float ur = smp.get_1d();
                 if (ur < p) div_assign(T, p); else break;
             }

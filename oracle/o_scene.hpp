@@ -103,6 +103,9 @@ struct Primitive {
     M4 local_to_world = M4::identity();
     M4 local_to_render = M4::identity();
     M4 render_to_local = M4::identity();   // used only by fast mode (hoisted inverse)
+    // DIAGNOSTIC lowering (Scene::render_space_lowering): this primitive's mesh with positions carried to render space once, the way the
+    // product lowers instances (csrc/scene.cpp), so that the two lowerings can be told apart in parity tests
+    std::shared_ptr<TriangleMesh> rs_mesh;
     bool is_light = false;
     uint32_t seq = 0;                      // creation order among all primitives
     std::vector<float> area_list, area_table;
@@ -250,6 +253,10 @@ struct Scene {
     std::vector<int> light_list;                  // LightSamplerFactory::light_list: >= 0 primitive index, < 0 delta light -1-k
     Bvh tlas;
     bool faithful = true;                         // see o_bvh.hpp
+    // DIAGNOSTIC (tests only; never the CPU baseline): intersect pre-transformed render-space triangles with the untransformed ray instead
+    // of transforming the ray into each primitive's local space (primitive/impls/triangle_mesh.rs:89-119).  Mathematically the same hit;
+    // numerically it rounds like the product's flat render-space BVH, which lets a test attribute GPU-vs-oracle path flips to the lowering.
+    bool render_space_lowering = false;
     bool built = false;
 
     // EmissiveTriangleMesh::new (emissive_triangle_mesh.rs:28-68)
@@ -282,6 +289,15 @@ struct Scene {
             if (p.is_light) { init_light(p); order.push_back({p.seq, (int)i}); }
         }
         for (auto& g : geometries) if (g->bvh.nodes.empty()) g->build();
+        for (auto& p : primitives) {
+            p.rs_mesh.reset();
+            if (!render_space_lowering) continue;
+            const TriangleMesh& g = *geometries[p.geometry];
+            p.rs_mesh = std::make_shared<TriangleMesh>();
+            p.rs_mesh->normals = g.normals; p.rs_mesh->tangents = g.tangents; p.rs_mesh->uvs = g.uvs; p.rs_mesh->indices = g.indices;
+            for (const V3& q : g.positions) p.rs_mesh->positions.push_back(transform_point3(p.local_to_render, q));
+            p.rs_mesh->build();
+        }
         tlas = Bvh::build((uint32_t)primitives.size(), [this](uint32_t i) {
             return transform_bounds(primitives[i].local_to_render, geometries[primitives[i].geometry]->bounds);
         });
@@ -313,6 +329,18 @@ struct Scene {
     // primitive/impls/triangle_mesh.rs:89-119 — ray to local (Mat4 inverse per call), hit back to render.
     bool primitive_intersect(uint32_t pi, const Ray& ray, float t_max, float* t_out, Intersection* out, Counters* c) const {
         const Primitive& p = primitives[pi];
+        if (p.rs_mesh) {                                         // diagnostic lowering: render-space triangles, the ray as it is
+            const TriangleMesh& g = *p.rs_mesh;
+            GeomHit gh;
+            auto item = [&](uint32_t t, const Ray& r, float tm, float* to, GeomHit* ho) { return g.tri_intersect(t, r, tm, to, ho); };
+            if (!g.bvh.intersect<GeomHit>(ray, t_max, item, !faithful, &gh, c ? &c->closest_blas : nullptr)) return false;
+            out->t_hit = gh.t_hit; out->wo = -ray.d; out->primitive = (int)pi; out->triangle = gh.index;
+            // positions and the geometric normal are already in render space; the shading normal / tangent come from LOCAL vertex data
+            out->interaction = SurfaceInteraction{gh.position, gh.normal, transform_normal(p.local_to_render, gh.shading_normal),
+                                                  transform_vector3(p.local_to_render, gh.tangent), gh.uv, p.material};
+            *t_out = gh.t_hit;
+            return true;
+        }
         const TriangleMesh& g = *geometries[p.geometry];
         M4 inv = faithful ? inverse(p.local_to_render) : p.render_to_local;
         Ray lr = transform_ray(inv, ray);
@@ -330,6 +358,11 @@ struct Scene {
     }
     bool primitive_intersect_p(uint32_t pi, const Ray& ray, float t_max, Counters* c) const {
         const Primitive& p = primitives[pi];
+        if (p.rs_mesh) {
+            const TriangleMesh& g = *p.rs_mesh;
+            auto item = [&](uint32_t t, const Ray& r, float tm) { return g.tri_intersect_p(t, r, tm); };
+            return g.bvh.intersect_p(ray, t_max, item, c ? &c->any_blas : nullptr);
+        }
         const TriangleMesh& g = *geometries[p.geometry];
         M4 inv = faithful ? inverse(p.local_to_render) : p.render_to_local;
         Ray lr = transform_ray(inv, ray);

@@ -55,6 +55,9 @@ extern "C" {
 int ptoracle_scene_create(ptoracle_scene** out) { *out = new ptoracle_scene(); return 0; }
 void ptoracle_scene_destroy(ptoracle_scene* s) { delete s; }
 int ptoracle_scene_set_faithful(ptoracle_scene* s, int faithful) { s->scene.faithful = faithful != 0; return 0; }
+// diagnostic, call before scene_build: 1 = pre-transformed render-space triangles (the product's lowering) instead of the reference's
+// per-primitive ray transform (o_scene.hpp Scene::render_space_lowering)
+int ptoracle_scene_set_lowering(ptoracle_scene* s, int render_space) { s->scene.render_space_lowering = render_space != 0; return 0; }
 
 int ptoracle_scene_set_rgb2spec(ptoracle_scene* s, const float* table, size_t n) {
     if (n != (size_t)(TBL + 3 * TBL * TBL * TBL * 3)) return -1;
@@ -158,7 +161,7 @@ static Camera make_camera(const mi355pt_camera* c) {
     return cam;
 }
 static RenderParams make_params(const mi355pt_camera* c, const mi355pt_params* p) {
-    RenderParams r; r.width = c->width; r.height = c->height; r.spp = p->spp; r.seed = p->seed; r.max_depth = p->max_depth;
+    RenderParams r; r.width = c->width; r.height = c->height; r.spp = p->spp; r.seed = p->seed; r.max_depth = p->max_depth; r.rr_gate = 1.0f - p->rr_gate_slack;
     r.strategy = p->strategy; r.sampler = p->sampler; r.exposure = p->exposure;
     return r;
 }
@@ -274,6 +277,20 @@ int ptoracle_probe_radiance(ptoracle_scene* s, const mi355pt_camera* c, const mi
     for (uint32_t i = 0; i < n; ++i) {
         Wavelengths wl; SS L = pt.trace(xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], &wl, nullptr);
         for (int k = 0; k < NS; ++k) { out_L[4 * i + k] = L.v[k]; out_lambda[4 * i + k] = wl.lambda[k]; out_pdf[4 * i + k] = wl.pdf[k]; }
+    }
+    return 0;
+}
+// probe_radiance + per-query diagnostic flags of PathTracer::trace (bit 0: a Russian-roulette gate on a knife edge)
+int ptoracle_probe_radiance_flags(ptoracle_scene* s, const mi355pt_camera* c, const mi355pt_params* p, const uint32_t* xys, uint32_t n,
+                                  float* out_L, float* out_lambda, float* out_pdf, uint8_t* out_flags) {
+    Camera cam = make_camera(c);
+    static const float zeros[3 * NLUT] = {0};
+    PathTracer pt{s->scene, cam, make_params(c, p), {zeros, zeros, zeros}};
+    for (uint32_t i = 0; i < n; ++i) {
+        Wavelengths wl; uint32_t fl = 0;
+        SS L = pt.trace(xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], &wl, nullptr, &fl);
+        for (int k = 0; k < NS; ++k) { out_L[4 * i + k] = L.v[k]; out_lambda[4 * i + k] = wl.lambda[k]; out_pdf[4 * i + k] = wl.pdf[k]; }
+        out_flags[i] = (uint8_t)fl;
     }
     return 0;
 }

@@ -49,6 +49,24 @@ class Oracle(ffi.Backend):
     def set_faithful(self, scene, faithful):
         self.lib.ptoracle_scene_set_faithful(scene.h, 1 if faithful else 0)
 
+    def set_render_space_lowering(self, scene, on=True):
+        """Diagnostic, BEFORE the scene is built (load_scene builds): the product's instance lowering instead of the reference's."""
+        self.lib.ptoracle_scene_set_lowering.argtypes = [C.c_void_p, C.c_int]
+        self.lib.ptoracle_scene_set_lowering(scene.h, 1 if on else 0)
+
+    def probe_radiance_flags(self, scene, cam, params, xys):
+        """probe_radiance + diagnostic flags per query (bit 0: a Russian-roulette gate `p >= 1` with p within 2 ulp of 1)."""
+        xys = np.ascontiguousarray(xys, dtype=np.uint32).reshape(-1, 3)
+        n = xys.shape[0]
+        L = np.zeros((n, 4), np.float32); lam = np.zeros((n, 4), np.float32); pdf = np.zeros((n, 4), np.float32); fl = np.zeros(n, np.uint8)
+        fp = C.POINTER(C.c_float)
+        self.lib.ptoracle_probe_radiance_flags.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.Params), C.POINTER(C.c_uint32), C.c_uint32,
+                                                            fp, fp, fp, C.POINTER(C.c_uint8)]
+        rc = self.lib.ptoracle_probe_radiance_flags(scene.h, C.byref(cam), C.byref(params), ffi._ptr(xys, C.c_uint32), n, ffi._ptr(L, C.c_float),
+                                                    ffi._ptr(lam, C.c_float), ffi._ptr(pdf, C.c_float), ffi._ptr(fl, C.c_uint8))
+        assert rc == 0
+        return L, lam, pdf, fl
+
     def render_accum(self, scene, cam, params, s_begin=0, s_end=None, threads=None, counters=False, accum=None):
         s_end = params.spp if s_end is None else s_end
         if accum is None:

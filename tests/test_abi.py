@@ -20,7 +20,7 @@ def test_struct_layouts_match_header(pkg):
     assert ctypes.sizeof(f.Spectrum) == 20
     assert ctypes.sizeof(f.MaterialDesc) == 4 + 20 + 4 + 4 + 4 + 20 + 4 + 4 + 5 * 4 + 20 + 20 + 12
     assert ctypes.sizeof(f.Camera) == 48
-    assert ctypes.sizeof(f.Params) == 36
+    assert ctypes.sizeof(f.Params) == 40
     assert ctypes.sizeof(f.Stats) == 11 * 8 + 10 * 8 + 8 + 8 + 8 * 8
 
 

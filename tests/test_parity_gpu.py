@@ -83,14 +83,22 @@ def test_secondary_ray_hit_parity(scenes3):
     # grazing rays are ill-conditioned in t (t = distance / cos): bound the bulk tightly, the tail loosely
     assert np.percentile(rel, 99.9) <= 5e-5, np.percentile(rel, 99.9)
     assert np.median(rel) <= 2e-7
-    # any-hit agrees with closest-hit distance on both sides
+    # any-hit agrees with closest-hit on BOTH sides: within t_max there is an occluder exactly when that side's own closest hit lies
+    # within t_max.  (Round 1 compared the GPU's any-hit with the ORACLE's closest-hit distance and allowed three mismatches: the one
+    # that occurs — tools/anyhit_probe.py, ray 48787 — is a ray 1e-6 above the wall it starts on, grazing at cos 1e-3; both sides hit
+    # the same triangle, the GPU at t = 5.6e-4, the oracle at 1.8e-3, because the reference moves the ray into the primitive's local
+    # space first (origin + camera position, one rounding of 5e-7 on a distance of 1e-6, primitive/impls/triangle_mesh.rs:97) while the
+    # product intersects render-space triangles.  Each side is consistent with itself, which is what any-hit has to guarantee.)
     tm = np.where(tc > 0, tc * 0.5, 1e30).astype(np.float32)
-    # (a handful of rays start within rounding distance of an edge: the conservative t > 0 test may differ there)
-    assert scenes3["cpu"][0].probe_occluded(o2, d2, tm).sum() == 0
-    assert scenes3["gpu"][0].probe_occluded(o2, d2, tm).sum() <= 3
+    og, oc = scenes3["gpu"][0].probe_occluded(o2, d2, tm), scenes3["cpu"][0].probe_occluded(o2, d2, tm)
+    assert np.array_equal(og != 0, (tg > 0) & (tg <= tm))
+    assert np.array_equal(oc != 0, (tc > 0) & (tc <= tm))
+    well = both & (np.abs(tg - tc) <= 1e-3 * np.abs(tc))                       # rays whose hit distance is well conditioned
+    assert np.array_equal(og[well], oc[well])
     tm2 = np.where(tc > 0, tc * 1.5, 1e30).astype(np.float32)
     og = scenes3["gpu"][0].probe_occluded(o2, d2, tm2)
     oc = scenes3["cpu"][0].probe_occluded(o2, d2, tm2)
+    assert np.array_equal(og != 0, (tg > 0) & (tg <= tm2)) and np.array_equal(oc != 0, (tc > 0) & (tc <= tm2))
     assert (og == oc).mean() >= 0.9999 and og.sum() >= (tc > 0).sum() * 0.999
 
 
@@ -123,27 +131,73 @@ def test_image_parity_scene3_mis_sobol(scenes3, product, oracle, pkg):
     assert (np.abs(qg.astype(int) - qc.astype(int)) <= 1).mean() >= 0.97
 
 
-@pytest.mark.parametrize("scene_id,strategy", [(3, "mis"), (3, "nee"), (0, "mis"), (5, "pt"), (17, "nee"), (17, "mis"), (6, "mis"), (8, "mis"),
-                                               (10, "mis"), (16, "mis"), (15, "mis"), (1, "nee"), (7, "mis")])
+# limits: (rmse of the tone-mapped frames, pixels off by more than 0.01) — default (5e-4, 6); measured values in tools/frame_table.py's
+# output (profiles/r02_frame_table.jsonl): 1e-7 .. 9e-5 and 0 pixels for every pair on the default bar
+FRAME_LIMITS = {
+    7: (2e-3, 24),      # rough gold: grazing microfacet samples amplify last-bit differences of libm (7e-4 / 8 measured)
+    11: (8e-3, 120),    # rough SF11 glass, NEE (3.5e-3 / 45 measured); the MIS frame has NaN pixels (see the radiance test) and is not compared
+    12: (8e-3, 80),     # four rough BK7 heroes (3.4e-3 / 25): GGX visible-normal sampling near the rim of the disk, pz = sqrt(1 - px^2 - py^2),
+    27: (0.03, 150),    # cancels catastrophically, so a 1-ulp sin/cos difference between device and host libm moves the sampled normal
+}
+KNIFE_EDGE_SCENES = (9, 13, 19)   # solid constant-eta plastic: compared with the Russian-roulette gate relaxed on both sides (next test)
+
+
+@pytest.mark.parametrize("scene_id,strategy", [(0, "mis"), (0, "nee"), (1, "nee"), (2, "mis"), (3, "mis"), (3, "nee"), (3, "pt"), (4, "mis"), (5, "pt"),
+                                               (5, "nee"), (6, "mis"), (7, "mis"), (7, "nee"), (8, "mis"), (9, "mis"), (10, "mis"), (11, "nee"),
+                                               (12, "mis"), (13, "mis"), (14, "nee"), (15, "mis"), (16, "mis"), (17, "nee"), (17, "mis"), (18, "nee"),
+                                               (19, "mis"), (19, "pt"), (19, "nee"), (20, "mis"), (20, "pt"), (21, "mis"), (21, "nee"), (22, "mis"),
+                                               (22, "nee"), (27, "mis"), (27, "nee"), (27, "pt")])
 def test_frames_match_the_oracle_sample_for_sample(product, oracle, pkg, scene_id, strategy):
-    """Outside rough refraction nothing amplifies a last-bit difference, so GPU and oracle must trace the SAME paths for all but a
-    handful of samples (diffuse, smooth glass / plastic / gold, clearcoat, point lights; rough gold with a wider margin): at 64 spp the tone-mapped frames agree to 5e-4 RMSE with at most 0.2 % of the pixels off by more than 0.01.
-    (The per-sample test above allows 1 % of diverging samples; a systematic fault inside that allowance — e.g. a throughput that rounds
+    """Every scene id of the radiance test, through the scene's own kernel specialisation (= what bench.py runs for it).  Outside rough
+    refraction nothing amplifies a last-bit difference, so GPU and oracle must trace the SAME paths for all but a handful of samples:
+    at 64 spp the tone-mapped frames agree to 5e-4 RMSE with at most 0.2 % of the pixels off by more than 0.01.
+    (The per-sample test allows 1 % of diverging samples; a systematic fault inside that allowance — e.g. a throughput that rounds
     differently for albedo 1 and so changes the Russian-roulette gate `p >= 1`, which shifts every later Sobol dimension — shows up
-    here as tens of wrong pixels.)"""
+    here as tens of wrong pixels.)  Scenes with a solid constant-eta plastic hero sit on exactly that gate BY THEIR PHYSICS (see
+    test_solid_plastic_flips_are_the_roulette_gate): they are compared with the gate relaxed by 1e-5 on both sides."""
     pair = {}
     for name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()
         pair[name] = (sc, pkg.scenes.load_scene(sc, scene_id, 64, 48, tex_size=128))
     oracle.set_faithful(pair["cpu"][0], False)
-    prm = pkg.make_params(64, strategy, "sobol")
+    prm = pkg.make_params(64, strategy, "sobol", rr_gate_slack=1e-5 if scene_id in KNIFE_EDGE_SCENES else 0.0)
     g = product.render(pair["gpu"][0], pair["gpu"][1], prm)
     c = oracle.render(pair["cpu"][0], pair["cpu"][1], prm)
     rmse = float(np.sqrt(np.mean((g - c) ** 2)))
     off = int((np.abs(g - c).max(axis=2) > 0.01).sum())
-    # (rough gold, scene 7: grazing microfacet samples amplify last-bit differences of libm; 8 pixels / 7e-4 measured)
-    lim_rmse, lim_off = (2e-3, 24) if scene_id == 7 else (5e-4, 6)
+    lim_rmse, lim_off = FRAME_LIMITS.get(scene_id, (5e-4, 6))
     assert rmse <= lim_rmse and off <= lim_off, (rmse, off)
+
+
+@pytest.mark.parametrize("scene_id", [9, 13])
+def test_solid_plastic_flips_are_the_roulette_gate(product, oracle, pkg, scene_id):
+    """Root cause of the round-1 'open divergence' on the solid plastic heroes (scene_9.rs, scene_13.rs): a specular REFLECTION off a
+    constant-eta dielectric returns f = F and pdf = F / (F + (1 - F)) (dielectric.rs:380-466), so the throughput becomes
+    T * (F * (1 / pdf)) = 1 or 1 - 1 ulp depending on the last bit of F — and apply_russian_roulette (base_renderer.rs:76-92) draws
+    its random number only if max(T) < 1.  The product builds shading frames from cross products and uses the transpose as the inverse,
+    the reference inverts a Mat4 numerically: cos(theta) differs in the last ulp for a share of the vertices, F with it, the gate falls
+    the other way and every later Sobol dimension of that sample shifts (a different but equally valid path).  Proof by intervention:
+    with the gate relaxed to max(T) >= 1 - 1e-5 on BOTH sides (mi355pt_params.rr_gate_slack) the two implementations trace the same
+    paths again; with the reference's gate the share of flipped samples is what tools/divergence_probe.py measured (0.29 % / 0.09 %,
+    first differing depth spread evenly over the path: profiles/r02_divergence_scene{9,13}.json).  Dispersive glass (scene 8: F differs
+    per wavelength, max(T) > 1) and the thin film (scene 10: pdf is the cumulative reflectance, T < 1) are nowhere near the gate."""
+    pair = {}
+    for name, be in (("gpu", product), ("cpu", oracle)):
+        sc = be.new_scene()
+        pair[name] = (sc, pkg.scenes.load_scene(sc, scene_id, 64, 48, tex_size=128))
+    oracle.set_faithful(pair["cpu"][0], False)
+    ys, xs, ss = np.meshgrid(np.arange(48), np.arange(64), np.arange(64), indexing="ij")
+    xys = np.stack([xs.ravel(), ys.ravel(), ss.ravel()], 1).astype(np.uint32)
+    share = {}
+    for slack in (0.0, 1e-5):
+        prm = pkg.make_params(64, "mis", "sobol", rr_gate_slack=slack)
+        Lg, lg, pg = pair["gpu"][0].probe_radiance(pair["gpu"][1], prm, xys)
+        Lc, lc, pc = pair["cpu"][0].probe_radiance(pair["cpu"][1], prm, xys)
+        assert np.array_equal(lg, lc) and np.array_equal(pg, pc)
+        share[slack] = float((~np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)).mean())
+    assert share[1e-5] <= 1e-4, share            # measured 1e-5 (2 of 196 608 samples) / 0
+    assert share[0.0] <= 6e-3, share             # measured 2.9e-3 / 8.9e-4: the reference's own gate, flipped by last-ulp differences
+    assert share[0.0] >= 10 * share[1e-5]
 
 
 def test_config1_pt_random(scenes3, product, oracle, pkg):
@@ -155,10 +209,12 @@ def test_config1_pt_random(scenes3, product, oracle, pkg):
     assert linear_rmse_u8(qg, qc) <= 0.01
 
 
-def test_gpu_pt_nee_mis_consistency(product, pkg):
-    """renderer_consistency_test.rs:319-353 on the GPU at the reference's own size: 200x150, 2048 spp, random."""
+@pytest.mark.parametrize("scene_id", [3, 5])
+def test_gpu_pt_nee_mis_consistency(product, pkg, scene_id):
+    """renderer_consistency_test.rs:319-353 on the GPU at the reference's own size: 200x150, 2048 spp, random — both scenes the
+    reference runs (scene 3 :319-335, scene 5 :337-352)."""
     sc = product.new_scene()
-    cam = pkg.scenes.load_scene(sc, 3, 200, 150, tex_size=256)
+    cam = pkg.scenes.load_scene(sc, scene_id, 200, 150, tex_size=256)
     imgs = {s: median3(product.quantize_u8(product.render(sc, cam, pkg.make_params(2048, s, "random")))) for s in ("pt", "nee", "mis")}
     assert gamma22_rmse_u8(imgs["pt"], imgs["nee"]) <= 0.013
     assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
@@ -219,14 +275,15 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
         assert 0.5 * nan_c.sum() <= nan_g.sum() <= 2.0 * nan_c.sum(), (nan_g.sum(), nan_c.sum())
     assert np.all(lg[nan_g, 0] < 370.0) and np.all(lc[nan_c, 0] < 370.0)
     assert abs(Lg[~bad, 0].mean() - Lc[~bad, 0].mean()) <= 0.02 * Lc[~bad, 0].mean()
-    # the render path uses a kernel specialised for the scene's materials (probes use the all-features build):
+    # (the probe is the per-sample log of the scene's own kernel specialisation, written by the production launch)
     # compare a small image too (reference metric, regression_test.rs:6-40)
-    prm8 = pkg.make_params(8, strategy, "sobol")
+    # (solid constant-eta plastic heroes: Russian-roulette gate relaxed on both sides, see test_solid_plastic_flips_are_the_roulette_gate)
+    prm8 = pkg.make_params(8, strategy, "sobol", rr_gate_slack=1e-5 if scene_id in KNIFE_EDGE_SCENES else 0.0)
     qg = product.quantize_u8(product.render(pair["gpu"][0], pair["gpu"][1], prm8))
     qc = oracle.quantize_u8(oracle.render(pair["cpu"][0], pair["cpu"][1], prm8))
-    # 8-spp frames: a refracted path that flips at a geometric edge moves its pixel by a lot (solid dielectric heroes), and a NaN
-    # sample blacks out its pixel (`as u8`, scene 11)
-    tol = {11: 0.03, 9: 0.02, 12: 0.02, 13: 0.02, 14: 0.02, 27: 0.02}.get(scene_id, 0.01)
+    # 8-spp frames of ROUGH refraction: GGX normal sampling near the rim of the disk amplifies 1-ulp libm differences (FRAME_LIMITS), and a
+    # NaN sample blacks out its pixel (`as u8`, scene 11); everything else is on the 0.01 bar
+    tol = {11: 0.03, 12: 0.02, 27: 0.02}.get(scene_id, 0.01)
     assert linear_rmse_u8(qg, qc) <= tol
 
 
@@ -400,6 +457,61 @@ def test_launch_shape_does_not_change_the_frame(product, oracle, pkg, scene_id, 
         # (solid glass: a refracted path that flips at an edge or at a Russian-roulette threshold moves its pixel by a lot; the
         # reference's own regression thresholds are 0.05-0.085, regression_test.rs:109-659)
         assert linear_rmse_u8(product.quantize_u8(img_g), oracle.quantize_u8(img_o)) <= (0.02 if scene_id == 8 else 0.01)
+
+
+# (name, scene, W, H, spp, strategy, shard_count): every BASELINE.json config at its TRUE size; the shard holds 4-9 tiles spread over the frame
+BASELINE_CONFIGS = [("C2", 3, 1920, 1080, 1024, "mis", 4001), ("C3", 10, 1920, 1080, 4096, "mis", 4001),
+                    ("C4", 8, 4096, 4096, 1024, "mis", 30011), ("C5", 17, 1920, 1080, 16384, "nee", 8009)]
+
+
+@pytest.mark.parametrize("name,scene_id,w,h,spp,strategy,shard_count", BASELINE_CONFIGS, ids=[c[0] for c in BASELINE_CONFIGS])
+def test_baseline_configs_at_true_size_match_the_oracle(product, oracle, pkg, name, scene_id, w, h, spp, strategy, shard_count):
+    """The RENDER kernel against the oracle at each BASELINE config's true resolution and spp, where C3 / C4 / C5's u32 Morton index
+    truncates (z_sobol_sampler.rs:198-201: 2 log2(res) + log2(spp) = 34 / 34 / 36 bits) and distant pixels share sample sequences.
+    One sparse shard (the tile through the frame centre, i.e. on the hero, and every shard_count-th tile from there: tiles beyond x or
+    y = 1024 / 2048, where dropped Morton bits matter) is rendered over the WHOLE sample range by the production launch path — the
+    2x2-block / single-pixel work items, the LDS Sobol prefix tables incl. sample_prefix_digits, and for C5 the split into launches of
+    4 096 sample indices — with the per-sample log on, and by the oracle's render_accum on the same shard.  Film: resolved shard pixels
+    to the frame-test bar.  Samples: a seeded subset of the log against the oracle's per-sample radiance, wavelengths bit-equal."""
+    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
+    centre = (tiles_y // 2) * tiles_x + tiles_x // 2
+    shard_index = centre % shard_count
+    tiles = np.arange(shard_index, tiles_x * tiles_y, shard_count)
+    tx, ty = tiles % tiles_x, tiles // tiles_x
+    assert 4 <= len(tiles) <= 9 and centre in tiles
+    assert (tx * 8 >= w // 2).any() and (ty * 8 >= h // 2).any()          # pixels whose high Morton bits are set
+    pair = {}
+    for be_name, be in (("gpu", product), ("cpu", oracle)):
+        sc = be.new_scene()
+        pair[be_name] = (sc, pkg.scenes.load_scene(sc, scene_id, w, h, tex_size=256))
+    oracle.set_faithful(pair["cpu"][0], False)
+    prm = pkg.make_params(spp, strategy, "sobol", shard_index=shard_index, shard_count=shard_count)
+    L, lam, pdf, film_g = product.render_sample_log(pair["gpu"][0], pair["gpu"][1], prm, 0, spp, want_accum=True)
+    assert L.shape == (len(tiles), 64, spp, 4)
+    film_c, _ = oracle.render_accum(pair["cpu"][0], pair["cpu"][1], prm, 0, spp, threads=min(os.cpu_count() or 1, 16))
+    mask = np.zeros((h, w), bool)
+    for x0, y0 in zip(tx * 8, ty * 8):
+        mask[y0:y0 + 8, x0:x0 + 8] = True
+    assert not film_g[~mask].any() and not film_c[~mask].any()             # nothing outside the shard's tiles
+    rg, rc = oracle.film_resolve(film_g[mask], spp), oracle.film_resolve(film_c[mask], spp)
+    rmse = float(np.sqrt(np.mean((rg - rc) ** 2)))
+    off = int((np.abs(rg - rc).max(axis=1) > 0.01).sum())
+    assert film_c[mask].mean() > 0.01 * spp and rmse <= 5e-4 and off <= 2, (rmse, off)
+    # the log's film is the film: summing the logged samples' sensor responses is what add_sample did (spot check through the oracle's resolve
+    # is not possible per sample, so compare per-sample radiance instead)
+    rng = np.random.default_rng(spp + scene_id)
+    n = 6000
+    k, pix, s = rng.integers(0, len(tiles), n), rng.integers(0, 64, n), rng.integers(0, spp, n)
+    s[:64] = spp - 1 - np.arange(64) % 8                                   # the top of the sample range (last launch of a split job)
+    xs, ys = tx[k] * 8 + pix % 8, ty[k] * 8 + pix // 8
+    keep = (xs < w) & (ys < h)
+    k, pix, s, xs, ys = k[keep], pix[keep], s[keep], xs[keep], ys[keep]
+    xys = np.stack([xs, ys, s], 1).astype(np.uint32)
+    Lc, lc, pc = pair["cpu"][0].probe_radiance(pair["cpu"][1], pkg.make_params(spp, strategy, "sobol"), xys)
+    Lg, lg, pg = L[k, pix, s], lam[k, pix, s], pdf[k, pix, s]
+    assert np.array_equal(lg, lc) and np.array_equal(pg, pc)               # wavelengths and termination: straight from the Sobol bits
+    close = np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)
+    assert close.mean() >= 0.999, close.mean()
 
 
 def test_dielectric_roughness_map_is_used(product, oracle, pkg):

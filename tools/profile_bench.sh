@@ -1,49 +1,88 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/profile_bench.sh <tag> [bench.py args...]
 # 1. rocprofv3 --kernel-trace --stats around bench.py (per-kernel time)
-# 2. separate --pmc passes (never combined with tracing): FETCH_SIZE, then WRITE_SIZE + L2 hit/miss
-# Writes gpurun_out/prof_<tag>/{kernel_stats.csv,pmc_traffic.json}; copy what should be judged into profiles/.
+# 2. separate --pmc passes (never combined with tracing): FETCH_SIZE; WRITE_SIZE + L2 hit/miss; SQ VALU / wait counters
+# Writes gpurun_out/prof_<tag>/{kernel_stats.csv,pmc_traffic.json,pmc_valu.json}; copy what should be judged into profiles/.
+# Every pass is checked: a failing pass stops the script with the tail of its log.
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=$1; shift
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 4 --warmup 1 --no-cpu-baseline $@"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/pmc_write.log 2>&1 || { tail -5 $OUT/pmc_write.log; exit 1; }
-python3 - "$OUT" "$ARGS" <<'PY'
-import csv, glob, sys, collections, json, shutil
-out_dir, args = sys.argv[1], sys.argv[2]
-res = {"command": "python3 bench.py " + args, "kernel": "pt_kernel<false,false,FEAT> (the timed launches: grid >= 1024 workgroups)"}
-# ---- kernel stats
+pass() {   # pass <dir> <rocprofv3 options...>
+  local d=$1; shift
+  timeout -k 10 400 rocprofv3 "$@" --output-format csv -d $OUT/$d -- python3 $R/bench.py $ARGS > $OUT/$d.log 2>&1 || { echo "pass $d failed"; tail -5 $OUT/$d.log; exit 1; }
+}
+pass trace --kernel-trace --stats
+pass pmc_fetch --pmc FETCH_SIZE
+pass pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+pass pmc_sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
+pass pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM
+pass pmc_grbm --pmc GRBM_GUI_ACTIVE
+python3 - "$OUT" "$ARGS" "$R" <<'PY'
+import csv, glob, sys, collections, json, shutil, re
+out_dir, args, root = sys.argv[1], sys.argv[2], sys.argv[3]
+IS_PT = lambda name: "pt_kernel<false" in name          # the production variants (the instrumented one is pt_kernel<true, ...>)
+line = None
+for l in open(out_dir + "/trace.log"):
+    if l.startswith("{") and '"metric"' in l:
+        line = json.loads(l)
+res = {"command": "python3 bench.py " + args, "kernel": "pt_kernel<false,FEAT,MODE> (the timed launches)"}
+if line:
+    m = re.match(r"scene(\d+) (\d+)x(\d+) (\w+)\+(\w+), (\d+)-spp job, (\d+) sample", line["config"]["workload"])
+    res["workload"] = {"scene": int(m.group(1)), "width": int(m.group(2)), "height": int(m.group(3)), "spp": int(m.group(6)),
+                       "spp_per_step": int(m.group(7)), "strategy": m.group(4), "sampler": m.group(5), "n_gpus": line["n_gpus"]}
+    res["samples_per_launch"] = line["config"]["samples_per_step"] // line["n_gpus"]
+    res["bench_line"] = line
+sys.path.insert(0, root)
+import importlib
+res["library"] = importlib.import_module("toy-cpu-pathtracing_amd").Product().version()
 for f in glob.glob(out_dir + "/trace/*/*_kernel_stats.csv"):
     shutil.copy(f, out_dir + "/kernel_stats.csv")
     for r in csv.DictReader(open(f)):
-        if r["Name"].startswith("void pt::pt_kernel<false, false") or "pt_kernel<false, false" in r["Name"]:
+        if IS_PT(r["Name"]):
             res.setdefault("kernel_stats", []).append({k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage")})
-# per-launch durations of the timed launches (skip the warmup launch and the 4-sample STATS launch, which is another kernel)
 for f in glob.glob(out_dir + "/trace/*/*_kernel_trace.csv"):
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "pt_kernel<false, false" in r["Kernel_Name"]]
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if IS_PT(r["Kernel_Name"])]
     if d:
         res["launches_ns"] = d
         res["avg_launch_ms_excluding_warmup"] = sum(d[1:]) / max(len(d) - 1, 1) / 1e6
-# ---- counters: per launch averages over the timed launches
-cnt = collections.defaultdict(list)
-for f in sorted(glob.glob(out_dir + "/pmc_*/*/*_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        if "pt_kernel<false, false" in r["Kernel_Name"]:
-            cnt[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in cnt.items():
-    res[k + "_per_launch"] = sum(v[1:]) / max(len(v) - 1, 1)
-if "FETCH_SIZE_per_launch" in res and "WRITE_SIZE_per_launch" in res:
+def counters(pattern):
+    cnt = collections.defaultdict(list)
+    for f in sorted(glob.glob(out_dir + "/" + pattern + "/*/*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if IS_PT(r["Kernel_Name"]):
+                cnt[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k + "_per_launch": sum(v[1:]) / max(len(v) - 1, 1) for k, v in cnt.items()}   # skip the warm-up launch
+traffic = dict(res); traffic.pop("bench_line", None)
+traffic.update(counters("pmc_fetch")); traffic.update(counters("pmc_write"))
+if "FETCH_SIZE_per_launch" in traffic and "WRITE_SIZE_per_launch" in traffic:
     # MI355X_MICROARCH.md (HBM): counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> double it
-    res["hbm_bytes_per_launch"] = (2.0 * res["FETCH_SIZE_per_launch"] + res["WRITE_SIZE_per_launch"]) * 1024.0
-    res["correction"] = "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950: FETCH_SIZE reports half of the fetched bytes]"
-if "TCC_HIT_sum_per_launch" in res:
-    h, m = res["TCC_HIT_sum_per_launch"], res["TCC_MISS_sum_per_launch"]
-    res["l2_hit_rate"] = h / max(h + m, 1.0)
-json.dump(res, open(out_dir + "/pmc_traffic.json", "w"), indent=1)
-print(json.dumps({k: v for k, v in res.items() if k != "launches_ns"}))
+    traffic["hbm_bytes_per_launch"] = (2.0 * traffic["FETCH_SIZE_per_launch"] + traffic["WRITE_SIZE_per_launch"]) * 1024.0
+    traffic["correction"] = "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950: FETCH_SIZE reports half of the fetched bytes]"
+if "TCC_HIT_sum_per_launch" in traffic:
+    h, m = traffic["TCC_HIT_sum_per_launch"], traffic["TCC_MISS_sum_per_launch"]
+    traffic["l2_hit_rate"] = h / max(h + m, 1.0)
+json.dump(traffic, open(out_dir + "/pmc_traffic.json", "w"), indent=1)
+valu = {k: res[k] for k in ("command", "kernel", "workload", "samples_per_launch", "library") if k in res}
+valu.update(counters("pmc_sq1")); valu.update(counters("pmc_sq2")); valu.update(counters("pmc_grbm"))
+if "SQ_INSTS_VALU_per_launch" in valu and "samples_per_launch" in valu:
+    ms = res.get("avg_launch_ms_excluding_warmup", 0.0)
+    iv = valu["SQ_INSTS_VALU_per_launch"]
+    valu["wave_instr_per_sample"] = iv / valu["samples_per_launch"]
+    valu["lane_use"] = valu["SQ_THREAD_CYCLES_VALU_per_launch"] / (64.0 * iv)
+    valu["unprofiled_launch_ms"] = ms
+    if ms:
+        valu["valu_Ginstr_per_s"] = iv / (ms * 1e-3) / 1e9
+        valu["issue_frac_of_1228.8G"] = valu["valu_Ginstr_per_s"] / 1228.8
+    wc = valu.get("SQ_WAVE_CYCLES_per_launch")
+    if wc:   # SQ_* cycle counters are in quad-cycles (MI355X_MICROARCH.md, cycle constants)
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"):
+            if k + "_per_launch" in valu:
+                valu["share_of_wave_cycles_" + k] = valu[k + "_per_launch"] / wc
+json.dump(valu, open(out_dir + "/pmc_valu.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in valu.items() if not k.endswith("_per_launch")}))
+print(json.dumps({k: v for k, v in traffic.items() if k in ("hbm_bytes_per_launch", "l2_hit_rate", "avg_launch_ms_excluding_warmup", "kernel_stats")}))
 PY
 tail -1 $OUT/trace.log

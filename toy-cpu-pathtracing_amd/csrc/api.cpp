@@ -127,6 +127,7 @@ DevParams make_params(const mi355pt_camera* cam, const mi355pt_params* p, uint32
     DevParams d{};
     d.spp = p->spp; d.seed = p->seed; d.max_depth = p->max_depth; d.strategy = p->strategy; d.sampler = p->sampler;
     d.exposure = p->exposure;
+    d.rr_gate = 1.0f - p->rr_gate_slack;
     d.log2_spp = log2_int(p->spp);                                              // ZSobolSampler::new (:179-196)
     uint32_t res = round_up_pow2(std::max(cam->width, cam->height));
     d.n_base4_digits = log2_int(res) + (d.log2_spp + 1) / 2;
@@ -166,6 +167,7 @@ int check_args(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_
     if (!s->impl.built) return fail(MI355PT_E_NOT_BUILT, "scene not built");
     if (cam->width == 0 || cam->height == 0 || p->spp == 0) return fail(MI355PT_E_INVALID, "empty image or spp == 0");
     if (p->strategy > 2 || p->sampler > 1) return fail(MI355PT_E_INVALID, "bad strategy/sampler");
+    if (!(p->rr_gate_slack >= 0.0f && p->rr_gate_slack < 1.0f)) return fail(MI355PT_E_INVALID, "rr_gate_slack must be in [0, 1)");
     if (p->shard_count && p->shard_index >= p->shard_count) return fail(MI355PT_E_INVALID, "bad shard");
     // mi355pt_scene_build bakes the world -> render translation (render space = world - camera position, camera.rs:84-86) into every
     // device record and uploads to the device that was current then: a render call must name the same camera position and device
@@ -184,7 +186,10 @@ mi355pt_scene::~mi355pt_scene() { delete ctx; }
 extern "C" {
 
 const char* mi355pt_last_error(void) { return g_err.c_str(); }
-const char* mi355pt_version(void) { return "mi355pt 0.1.0 (gfx950)"; }
+#ifndef MI355PT_BUILD_ID
+#define MI355PT_BUILD_ID "dev"
+#endif
+const char* mi355pt_version(void) { return "mi355pt 0.2.0 (gfx950) build " MI355PT_BUILD_ID; }
 
 int mi355pt_scene_create(mi355pt_scene** out) {
     if (!out) return fail(MI355PT_E_INVALID, "null out");

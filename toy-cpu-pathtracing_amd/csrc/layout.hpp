@@ -181,6 +181,7 @@ struct DevParams {
     uint32_t sample_prefix_digits;          // single-pixel items (b = 0) over aligned 4^m sample blocks: this many top base-4 digits of the
                                             // sample index are item-uniform too and join the Sobol prefix tables
     uint32_t stats_mode;                    // instrumented variant only: 1 = reference traversal order (canonical counts), 2 = production traversal
+    float rr_gate;                          // Russian roulette is skipped when max(T) >= rr_gate (1 = the reference; mi355pt_params.rr_gate_slack)
     float xyz_to_rgb[9];                    // row-major sRGB matrix (gamut.rs:50-63)
 };
 

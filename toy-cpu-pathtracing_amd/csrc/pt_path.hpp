@@ -339,7 +339,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             for (int i = 0; i < 4; ++i) T[i] = T[i] * (pf[i] * tf);
             // apply_russian_roulette (:76-92)
             float p = fmaxf(fmaxf(fmaxf(fmaxf(-INFINITY, T[0]), T[1]), T[2]), T[3]);
-            if (!(p >= 1.0f)) {
+            if (!(p >= prm.rr_gate)) {                                         // rr_gate = 1 (the reference) unless a test asks for slack
                 float ur = get_1d(smp, sctx);
                 if (ur < p) {
                     if (p != 0.0f) {

@@ -76,7 +76,7 @@ class Camera(C.Structure):
 class Params(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("seed", C.c_uint32), ("max_depth", C.c_uint32), ("strategy", C.c_uint32),
                 ("sampler", C.c_uint32), ("exposure", C.c_float), ("shard_index", C.c_uint32),
-                ("shard_count", C.c_uint32), ("collect_stats", C.c_uint32)]
+                ("shard_count", C.c_uint32), ("collect_stats", C.c_uint32), ("rr_gate_slack", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -97,8 +97,8 @@ def make_camera(position, direction, up, width, height, fov_deg=45.0):
 
 
 def make_params(spp, strategy="mis", sampler="sobol", seed=0, max_depth=16, exposure=1.0, shard_index=0, shard_count=1,
-                collect_stats=0):
-    return Params(spp, seed, max_depth, STRATEGY[strategy], SAMPLER[sampler], exposure, shard_index, shard_count, collect_stats)
+                collect_stats=0, rr_gate_slack=0.0):
+    return Params(spp, seed, max_depth, STRATEGY[strategy], SAMPLER[sampler], exposure, shard_index, shard_count, collect_stats, rr_gate_slack)
 
 
 def _ptr(a, ty):
