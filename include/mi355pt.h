@@ -198,12 +198,28 @@ int mi355pt_render(const mi355pt_scene* s, const mi355pt_camera* cam, const mi35
 int mi355pt_render_accum_device(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p,
                                 uint32_t sample_begin, uint32_t sample_end, float* d_accum, void* hip_stream,
                                 mi355pt_stats* stats /* NULL ok; non-NULL synchronises the stream */);
+/* The seam as main.rs:228 calls it — ONE call from ONE process — over several GPUs of the node (north star: "pixel tiles shard
+ * across the 8 GPUs of one node").  mi355pt_scene_build_multi replaces mi355pt_scene_build: the scene (< 30 MB) is replicated on
+ * every listed device (ids may repeat, which rehearses the path on fewer GPUs).  mi355pt_render_multi = mi355pt_render: the frame's
+ * 8x8 tiles are dealt round-robin to the devices (shard i of n, concurrent launches on per-device streams), the devices' linear
+ * films (Sensor.accumulated_rgb, sensor.rs:12-20) are gathered onto the first device by xGMI peer copies and added — disjoint
+ * tiles, so the sum is exact — then resolved there (Sensor::to_rgb) and copied to out_rgb.  The caller's current device is
+ * restored.  One process per GPU instead: mi355pt_render_accum_device with shard_index = rank + one RCCL reduce. */
+int mi355pt_scene_build_multi(mi355pt_scene* s, const mi355pt_camera* cam, int n_devices, const int* device_ids);
+int mi355pt_render_multi(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, float* out_rgb);
 /* Sensor::to_rgb on device buffers: mean over spp, clip, Reinhard, sRGB OETF.  sensor.rs:81-88, tone_map.rs:20-28 */
 int mi355pt_film_resolve_device(const float* d_accum, uint32_t n_pixels, uint32_t spp, float* d_out_rgb, void* hip_stream);
 /* RendererImage::save quantisation `(p*255.0) as u8`  renderer.rs:137-148 (host helper) */
 int mi355pt_quantize_u8(const float* rgb, size_t n, uint8_t* out);
 
 /* ---------------- probes (parity tests; same device code as the render path) ---------------- */
+/* The built acceleration structure as the device holds it (no reference counterpart; the reference's is scene/src/bvh.rs:300-343):
+ * node records of 64 B {bx[4] = lo0.x lo1.x hi0.x hi1.x, by[4], bz[4], int32 child[2] (>= 0 node index, < 0 leaf:
+ * first = (c & 0x7fffffff) >> 3, count = (c & 7) + 1), pad[2]} and leaf-ordered render-space triangle records of 48 B
+ * {p0 p1 p2 as 9 floats, pad[3]}.  Call with NULL buffers for the counts; *n_nodes / *n_tris hold the buffer capacities on
+ * entry.  The parity tests hand the tree to the oracle, which walks it to check the instrumented kernel's step counts. */
+int mi355pt_scene_export_bvh(const mi355pt_scene* s, void* out_nodes, uint32_t* n_nodes, void* out_tris, uint32_t* n_tris,
+                             int32_t* root);
 /* ZSobolSampler: for each query (x, y, sample_index) emit n_dims raw 32-bit Sobol outputs following the draw
  * pattern string `pattern` of '1' (get_1d) and '2' (get_2d) characters.  z_sobol_sampler.rs:198-230 */
 int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t seed, const uint32_t* xys /* n*3 */,

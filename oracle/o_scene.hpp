@@ -227,13 +227,73 @@ struct EnvLight {
     }
 };
 
+// The PRODUCT's flat BVH2 (csrc/layout.hpp DevNode / DevTri, handed over by mi355pt_scene_export_bvh) walked in the plain order of
+// csrc/pt_device.hpp trace_closest / trace_any — near child first, pruned by the best distance, a per-ray stack; any-hit: child 0 first,
+// first hit ends the walk — ONLY to count node and triangle steps for the rays the oracle traces.  It checks the instrumented kernel's
+// self-counted work (SURVEY 8d "counts must agree within 2 %") with an independent implementation; hits still come from the oracle's
+// own two-level BVH.
+struct FlatBvh {
+    struct Node { float bx[4], by[4], bz[4]; int32_t child[2]; uint32_t pad[2]; };      // 64 B, = DevNode
+    struct Tri { float v[9]; uint32_t pad[3]; };                                         // 48 B, = DevTri (p0 p1 p2 packed)
+    std::vector<Node> nodes; std::vector<Tri> tris; int32_t root = 0;
+    bool valid() const { return !tris.empty(); }
+    static uint32_t leaf_first(int32_t c) { return ((uint32_t)c & 0x7fffffffu) >> 3; }
+    static uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1; }
+    static bool slab(const Node& n, int i, const Ray& r, V3 inv, float t_max, float* t_near) {
+        float lx = (n.bx[i] - r.o.x) * inv.x, hx = (n.bx[2 + i] - r.o.x) * inv.x;
+        float ly = (n.by[i] - r.o.y) * inv.y, hy = (n.by[2 + i] - r.o.y) * inv.y;
+        float lz = (n.bz[i] - r.o.z) * inv.z, hz = (n.bz[2 + i] - r.o.z) * inv.z;
+        float tn = std::fmax(std::fmax(std::fmin(lx, hx), std::fmin(ly, hy)), std::fmax(std::fmin(lz, hz), 0.0f));
+        float tf = std::fmin(std::fmin(std::fmax(lx, hx), std::fmax(ly, hy)), std::fmin(std::fmax(lz, hz), t_max));
+        *t_near = tn;
+        return tn <= tf;
+    }
+    void walk(const Ray& r, float t_max, bool any_hit, TraversalCounters* c) const {
+        V3 inv{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+        float t_best = t_max;
+        int32_t stack[64]; int sp = 0;
+        int32_t cur = root;
+        for (;;) {
+            if (cur >= 0) {
+                const Node& n = nodes[(size_t)cur];
+                c->nodes++;
+                float n0, n1;
+                bool h0 = slab(n, 0, r, inv, t_best, &n0), h1 = slab(n, 1, r, inv, t_best, &n1);
+                if (h0 && h1) {
+                    bool first0 = any_hit ? true : n0 <= n1;
+                    stack[sp++] = first0 ? n.child[1] : n.child[0];
+                    cur = first0 ? n.child[0] : n.child[1];
+                    continue;
+                } else if (h0) { cur = n.child[0]; continue; }
+                else if (h1) { cur = n.child[1]; continue; }
+            } else {
+                uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const float* v = tris[first + i].v;
+                    V3 ps[3] = {V3{v[0], v[1], v[2]}, V3{v[3], v[4], v[5]}, V3{v[6], v[7], v[8]}};
+                    TriHit h;
+                    c->items++;
+                    if (intersect_triangle(r, t_best, ps, &h)) {
+                        if (any_hit) return;
+                        if (h.t < t_best) t_best = h.t;
+                    }
+                }
+            }
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+};
+
 struct Counters {
     TraversalCounters closest_tlas, closest_blas, any_tlas, any_blas;
+    TraversalCounters flat_closest, flat_any;     // steps through the product's exported tree (FlatBvh)
     uint64_t closest_rays = 0, shadow_rays = 0, closest_hits = 0, bounces = 0, samples = 0, sampler_draws = 0;
     uint64_t spectrum_evals = 0, textured_lookups = 0;
     void add(const Counters& o) {
         auto a = [](TraversalCounters& x, const TraversalCounters& y) { x.nodes += y.nodes; x.items += y.items; };
         a(closest_tlas, o.closest_tlas); a(closest_blas, o.closest_blas); a(any_tlas, o.any_tlas); a(any_blas, o.any_blas);
+        a(flat_closest, o.flat_closest); a(flat_any, o.flat_any);
         closest_rays += o.closest_rays; shadow_rays += o.shadow_rays; closest_hits += o.closest_hits;
         bounces += o.bounces; samples += o.samples; sampler_draws += o.sampler_draws;
         spectrum_evals += o.spectrum_evals; textured_lookups += o.textured_lookups;
@@ -252,6 +312,7 @@ struct Scene {
     uint32_t next_seq = 0;
     std::vector<int> light_list;                  // LightSamplerFactory::light_list: >= 0 primitive index, < 0 delta light -1-k
     Bvh tlas;
+    FlatBvh flat;                                 // the product's tree, for step counting only (empty unless handed over)
     bool faithful = true;                         // see o_bvh.hpp
     // DIAGNOSTIC (tests only; never the CPU baseline): intersect pre-transformed render-space triangles with the untransformed ray instead
     // of transforming the ray into each primitive's local space (primitive/impls/triangle_mesh.rs:89-119).  Mathematically the same hit;
@@ -372,6 +433,7 @@ struct Scene {
     // Scene::intersect / intersect_p (scene.rs:80-103)
     bool intersect(const Ray& ray, float t_max, Intersection* out, Counters* c) const {
         if (c) c->closest_rays++;
+        if (c && flat.valid()) flat.walk(ray, t_max, false, &c->flat_closest);
         auto item = [&](uint32_t pi, const Ray& r, float tm, float* to, Intersection* ho) {
             return primitive_intersect(pi, r, tm, to, ho, c);
         };
@@ -381,6 +443,7 @@ struct Scene {
     }
     bool intersect_p(const Ray& ray, float t_max, Counters* c) const {
         if (c) c->shadow_rays++;
+        if (c && flat.valid()) flat.walk(ray, t_max, true, &c->flat_any);
         auto item = [&](uint32_t pi, const Ray& r, float tm) { return primitive_intersect_p(pi, r, tm, c); };
         return tlas.intersect_p(ray, t_max, item, c ? &c->any_tlas : nullptr);
     }

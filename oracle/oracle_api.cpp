@@ -213,12 +213,21 @@ int ptoracle_quantize_u8(const float* rgb, size_t n, uint8_t* out) {      // ren
     }
     return 0;
 }
-void ptoracle_get_counters(ptoracle_scene* s, uint64_t* out /* 16 */) {
+void ptoracle_get_counters(ptoracle_scene* s, uint64_t* out /* 20 */) {
     const Counters& c = s->counters;
-    uint64_t v[16] = {c.samples, c.closest_rays, c.shadow_rays, c.closest_tlas.nodes, c.closest_tlas.items, c.closest_blas.nodes,
+    uint64_t v[20] = {c.samples, c.closest_rays, c.shadow_rays, c.closest_tlas.nodes, c.closest_tlas.items, c.closest_blas.nodes,
                       c.closest_blas.items, c.any_tlas.nodes, c.any_tlas.items, c.any_blas.nodes, c.any_blas.items,
-                      c.closest_hits, c.bounces, c.spectrum_evals, c.textured_lookups, c.sampler_draws};
+                      c.closest_hits, c.bounces, c.spectrum_evals, c.textured_lookups, c.sampler_draws,
+                      c.flat_closest.nodes, c.flat_closest.items, c.flat_any.nodes, c.flat_any.items};
     std::memcpy(out, v, sizeof(v));
+}
+// the product's flat BVH (mi355pt_scene_export_bvh: 64-B node records, 48-B triangle records, root link) for step counting (FlatBvh)
+int ptoracle_scene_set_flat_bvh(ptoracle_scene* s, const void* nodes, uint32_t n_nodes, const void* tris, uint32_t n_tris, int32_t root) {
+    static_assert(sizeof(FlatBvh::Node) == 64 && sizeof(FlatBvh::Tri) == 48, "record sizes of csrc/layout.hpp");
+    s->scene.flat.nodes.assign((const FlatBvh::Node*)nodes, (const FlatBvh::Node*)nodes + n_nodes);
+    s->scene.flat.tris.assign((const FlatBvh::Tri*)tris, (const FlatBvh::Tri*)tris + n_tris);
+    s->scene.flat.root = root;
+    return 0;
 }
 void ptoracle_reset_counters(ptoracle_scene* s) { s->counters = Counters(); }
 

@@ -88,14 +88,20 @@ class Oracle(ffi.Backend):
 
     COUNTER_NAMES = ["samples", "closest_rays", "shadow_rays", "closest_tlas_nodes", "closest_tlas_items", "closest_blas_nodes",
                      "closest_blas_items", "any_tlas_nodes", "any_tlas_items", "any_blas_nodes", "any_blas_items", "closest_hits",
-                     "bounces", "spectrum_evals", "textured_lookups", "sampler_draws"]
+                     "bounces", "spectrum_evals", "textured_lookups", "sampler_draws",
+                     "flat_closest_nodes", "flat_closest_tris", "flat_any_nodes", "flat_any_tris"]
 
     def counters(self, scene, reset=True):
-        v = (C.c_uint64 * 16)()
+        v = (C.c_uint64 * 20)()
         self.lib.ptoracle_get_counters(scene.h, v)
         if reset:
             self.lib.ptoracle_reset_counters(scene.h)
         return dict(zip(self.COUNTER_NAMES, [int(x) for x in v]))
+
+    def set_flat_bvh(self, scene, nodes, tris, root):
+        """Hand the product's exported tree (Product.export_bvh) to the oracle: it is walked for step COUNTING only."""
+        self.lib.ptoracle_scene_set_flat_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int32]
+        self.lib.ptoracle_scene_set_flat_bvh(scene.h, nodes.ctypes.data, nodes.shape[0], tris.ctypes.data, tris.shape[0], root)
 
     def sobol_index(self, width, height, spp, x, y, sample, dimension):
         out = C.c_uint64()

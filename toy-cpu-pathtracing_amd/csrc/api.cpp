@@ -17,6 +17,7 @@ struct PathOut { float* L; float* lam; float* pdf; uint32_t s_base, n_s; };   //
 hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, float*, unsigned*, DevStats*, bool, uint32_t, int, hipStream_t,
                      const PathOut&);
 hipError_t launch_resolve(const float*, uint32_t, uint32_t, float*, hipStream_t);
+hipError_t launch_film_add(float*, const float*, size_t, hipStream_t);
 hipError_t launch_probe_sobol(uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t*, hipStream_t);
 hipError_t launch_probe_intersect(const DevScene&, const float*, const float*, uint32_t, float*, uint32_t*, uint32_t*, float*, hipStream_t);
 hipError_t launch_probe_occluded(const DevScene&, const float*, const float*, const float*, uint32_t, uint8_t*, hipStream_t);
@@ -53,9 +54,22 @@ struct LaunchCtx {
     int next = 0;
     ~LaunchCtx() { (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); (void)hipFree(d_partial); }
 };
+// One device's share of a multi-device scene (mi355pt_scene_build_multi): a full replica of the scene on that device plus
+// the stream, film and event mi355pt_render_multi drives it with.  Replica 0 is the scene object itself.
+struct MultiPart {
+    int device = -1;
+    mi355pt_scene* scene = nullptr;      // owned unless it is the parent (part 0)
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    float* d_film = nullptr;             // full-frame linear film of this device's tile shard
+    float* d_stage = nullptr;            // part 0 only: staging copy of a peer's film
+    float* d_out = nullptr;              // part 0 only: resolved frame
+    size_t film_floats = 0;
+};
 struct mi355pt_scene {
     SceneImpl impl;
     mutable LaunchCtx* ctx = nullptr;
+    mutable std::vector<MultiPart> parts;   // empty unless built with mi355pt_scene_build_multi
     ~mi355pt_scene();
 };
 
@@ -181,7 +195,24 @@ int check_args(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_
 
 }  // namespace
 
-mi355pt_scene::~mi355pt_scene() { delete ctx; }
+static void free_parts(std::vector<MultiPart>& parts) {
+    for (size_t i = 0; i < parts.size(); ++i) {
+        MultiPart& m = parts[i];
+        (void)hipSetDevice(m.device);
+        if (m.stream) (void)hipStreamDestroy(m.stream);
+        if (m.done) (void)hipEventDestroy(m.done);
+        (void)hipFree(m.d_film); (void)hipFree(m.d_stage); (void)hipFree(m.d_out);
+        if (i > 0) delete m.scene;
+    }
+    parts.clear();
+}
+mi355pt_scene::~mi355pt_scene() {
+    int cur = 0;
+    const bool have = !parts.empty() && hipGetDevice(&cur) == hipSuccess;
+    free_parts(parts);
+    if (have) (void)hipSetDevice(cur);
+    delete ctx;
+}
 
 extern "C" {
 
@@ -505,6 +536,97 @@ int mi355pt_render_sample_log(const mi355pt_scene* s, const mi355pt_camera* cam,
     return MI355PT_OK;
 }
 
+// ---------------- several GPUs of one node behind ONE call (single process) ----------------
+// The reference calls the seam once from one process (renderer/src/main.rs:228).  mi355pt_scene_build_multi replicates the scene
+// on every listed device (the working set is < 30 MB); mi355pt_render_multi deals the frame's 8x8 tiles round-robin to the devices
+// (each launch on its own stream, concurrently), gathers the rank-local linear films onto the first device over xGMI peer copies
+// and adds them there — the tile shards are disjoint, so the sum is exact and its order fixed — then resolves and copies out.
+// No communicator is needed inside one process; the one-process-per-GPU path (bench.py, torch.distributed) reduces the same films
+// with RCCL.
+int mi355pt_scene_build_multi(mi355pt_scene* s, const mi355pt_camera* cam, int n_devices, const int* device_ids) {
+    if (!s || !cam || !device_ids || n_devices < 1 || n_devices > 64) return fail(MI355PT_E_INVALID, "bad device list");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI355PT_E_NO_DEVICE, "no HIP device: the product path requires a gfx950 GPU");
+    for (int i = 0; i < n_devices; ++i) if (device_ids[i] < 0 || device_ids[i] >= ndev) return fail(MI355PT_E_INVALID, "device id out of range");
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    free_parts(s->parts);
+    int rc = MI355PT_OK;
+    std::vector<MultiPart> parts((size_t)n_devices);
+    for (int i = 0; i < n_devices && rc == MI355PT_OK; ++i) {
+        MultiPart& m = parts[(size_t)i];
+        m.device = device_ids[i];
+        if (hipSetDevice(m.device) != hipSuccess) { rc = fail(MI355PT_E_DEVICE, "hipSetDevice failed"); break; }
+        if (i == 0) m.scene = s;
+        else {
+            m.scene = new (std::nothrow) mi355pt_scene();
+            if (!m.scene) { rc = fail(MI355PT_E_INVALID, "allocation failed"); break; }
+            SceneImpl& d = m.scene->impl; const SceneImpl& o = s->impl;       // the description, not the lowered state
+            d.table = o.table; d.luts = o.luts; d.textures = o.textures; d.meshes = o.meshes; d.mat_descs = o.mat_descs; d.materials = o.materials;
+            d.instances = o.instances; d.env = o.env; d.delta_lights = o.delta_lights; d.bvh_builder = o.bvh_builder;
+        }
+        rc = mi355pt_scene_build(m.scene, cam);
+        if (rc == MI355PT_OK && hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) != hipSuccess) rc = fail(MI355PT_E_DEVICE, "hipStreamCreate failed");
+        if (rc == MI355PT_OK && hipEventCreateWithFlags(&m.done, hipEventDisableTiming) != hipSuccess) rc = fail(MI355PT_E_DEVICE, "hipEventCreate failed");
+        if (rc == MI355PT_OK && i > 0 && m.device != parts[0].device) {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, parts[0].device, m.device);
+            if (can) { (void)hipSetDevice(parts[0].device); (void)hipDeviceEnablePeerAccess(m.device, 0); (void)hipGetLastError(); }   // already enabled is fine
+        }
+    }
+    (void)hipSetDevice(cur);
+    if (rc != MI355PT_OK) { std::string keep = g_err; free_parts(parts); g_err = keep; return rc; }
+    s->parts = std::move(parts);
+    return MI355PT_OK;
+}
+
+int mi355pt_render_multi(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_params* p, float* out_rgb) {
+    if (!s || !cam || !p || !out_rgb) return fail(MI355PT_E_INVALID, "null argument");
+    if (s->parts.empty()) return fail(MI355PT_E_NOT_BUILT, "scene not built with mi355pt_scene_build_multi");
+    if (p->shard_count > 1) return fail(MI355PT_E_INVALID, "mi355pt_render_multi shards the frame itself: pass shard_count 0 or 1");
+    if (p->collect_stats) return fail(MI355PT_E_INVALID, "collect_stats is a single-device diagnostic");
+    if (cam->width == 0 || cam->height == 0 || p->spp == 0) return fail(MI355PT_E_INVALID, "empty image or spp == 0");
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    std::vector<MultiPart>& parts = s->parts;
+    const uint32_t n = (uint32_t)parts.size();
+    const size_t film = (size_t)cam->width * cam->height * 3, film_pad = (film + 3) / 4 * 4;
+    int rc = MI355PT_OK;
+    auto hip_ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == MI355PT_OK) rc = fail(MI355PT_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
+    // 1. every device renders its tile shard into its own zeroed film, concurrently
+    for (uint32_t i = 0; i < n && rc == MI355PT_OK; ++i) {
+        MultiPart& m = parts[i];
+        if (!hip_ok(hipSetDevice(m.device), "hipSetDevice")) break;
+        if (m.film_floats != film_pad) {
+            (void)hipFree(m.d_film); (void)hipFree(m.d_stage); (void)hipFree(m.d_out); m.d_film = m.d_stage = m.d_out = nullptr; m.film_floats = 0;
+            if (!hip_ok(hipMalloc((void**)&m.d_film, film_pad * sizeof(float)), "hipMalloc film")) break;
+            if (i == 0 && n > 1 && !hip_ok(hipMalloc((void**)&m.d_stage, film_pad * sizeof(float)), "hipMalloc stage")) break;
+            if (i == 0 && !hip_ok(hipMalloc((void**)&m.d_out, film_pad * sizeof(float)), "hipMalloc out")) break;
+            m.film_floats = film_pad;
+        }
+        if (!hip_ok(hipMemsetAsync(m.d_film, 0, film_pad * sizeof(float), m.stream), "hipMemsetAsync")) break;
+        mi355pt_params q = *p;
+        q.shard_index = i; q.shard_count = n;
+        if ((rc = mi355pt_render_accum_device(m.scene, cam, &q, 0, p->spp, m.d_film, (void*)m.stream, nullptr))) break;
+        hip_ok(hipEventRecord(m.done, m.stream), "hipEventRecord");
+    }
+    // 2. gather onto the first device (peer copy over xGMI, then add: disjoint tiles, fixed order), resolve, copy out
+    if (rc == MI355PT_OK && hip_ok(hipSetDevice(parts[0].device), "hipSetDevice")) {
+        MultiPart& r = parts[0];
+        for (uint32_t i = 1; i < n && rc == MI355PT_OK; ++i) {
+            if (!hip_ok(hipStreamWaitEvent(r.stream, parts[i].done, 0), "hipStreamWaitEvent")) break;
+            if (!hip_ok(hipMemcpyPeerAsync(r.d_stage, r.device, parts[i].d_film, parts[i].device, film_pad * sizeof(float), r.stream), "hipMemcpyPeerAsync")) break;
+            hip_ok(launch_film_add(r.d_film, r.d_stage, film_pad, r.stream), "film add");
+        }
+        if (rc == MI355PT_OK) rc = mi355pt_film_resolve_device(r.d_film, cam->width * cam->height, p->spp, r.d_out, (void*)r.stream);
+        if (rc == MI355PT_OK) hip_ok(hipMemcpyAsync(out_rgb, r.d_out, film * sizeof(float), hipMemcpyDeviceToHost, r.stream), "hipMemcpyAsync");
+        if (rc == MI355PT_OK) hip_ok(hipStreamSynchronize(r.stream), "hipStreamSynchronize");
+    }
+    if (rc != MI355PT_OK) for (MultiPart& m : parts) { (void)hipSetDevice(m.device); (void)hipStreamSynchronize(m.stream); }   // nothing of this call stays in flight
+    (void)hipSetDevice(cur);
+    return rc;
+}
+
 int mi355pt_scene_info(const mi355pt_scene* s, char* buf, size_t n) {
     if (!s || !buf || n == 0) return fail(MI355PT_E_INVALID, "null argument");
     if (!s->impl.built) return fail(MI355PT_E_INVALID, "scene not built");
@@ -559,6 +681,17 @@ int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t 
     HIP_TRY(hipMemcpy(d_pat.p, pattern, n_pat, hipMemcpyHostToDevice));
     HIP_TRY(launch_probe_sobol(width, seed, log2_spp, nb4, d_xys.p, n, d_pat.p, n_pat, per, d_out.p, nullptr));
     HIP_TRY(hipMemcpy(out_bits, d_out.p, sizeof(uint32_t) * (size_t)n * per, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+
+int mi355pt_scene_export_bvh(const mi355pt_scene* s, void* out_nodes, uint32_t* n_nodes, void* out_tris, uint32_t* n_tris, int32_t* root) {
+    if (!s || !n_nodes || !n_tris) return fail(MI355PT_E_INVALID, "null argument");
+    if (!s->impl.built) return fail(MI355PT_E_NOT_BUILT, "scene not built");
+    const DevScene& d = s->impl.dev;
+    if (out_nodes) { if (*n_nodes < d.n_nodes) return fail(MI355PT_E_INVALID, "node buffer too small"); if (d.n_nodes) HIP_TRY(hipMemcpy(out_nodes, d.nodes, sizeof(DevNode) * d.n_nodes, hipMemcpyDeviceToHost)); }
+    if (out_tris) { if (*n_tris < d.n_tris) return fail(MI355PT_E_INVALID, "triangle buffer too small"); HIP_TRY(hipMemcpy(out_tris, d.tris, sizeof(DevTri) * d.n_tris, hipMemcpyDeviceToHost)); }
+    *n_nodes = d.n_nodes; *n_tris = d.n_tris;
+    if (root) *root = d.root;
     return MI355PT_OK;
 }
 

@@ -107,6 +107,16 @@ __global__ __launch_bounds__(64) void probe_occluded_kernel(DevScene sc, const f
 #include "experiments/probe_intersect_dyn.inc"
 #endif
 
+// dst += src over a film (multi-device gather: the films of the other devices' tile shards, disjoint from this device's own)
+__global__ void film_add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 a = ((const float4*)dst)[i], b = ((const float4*)src)[i];
+        ((float4*)dst)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
 // adds the per-chunk film tiles of a split launch to the film, in chunk order (one thread per pixel of each tile of the shard)
 __global__ void combine_kernel(DevCamera cam, DevParams prm, const float* __restrict__ partial, float* __restrict__ accum, uint32_t n_tiles) {
     const uint32_t tile_k = blockIdx.x, lane = threadIdx.x;
@@ -138,6 +148,12 @@ hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& 
         const uint32_t n_tiles = (prm.n_work / prm.chunks) >> (6u - 2u * prm.block_log2);   // n_work = tiles * blocks per tile * chunks
         hipLaunchKernelGGL(combine_kernel, dim3(n_tiles), dim3(64), 0, stream, cam, prm, (const float*)d_partial, d_accum, n_tiles);
     }
+    return hipGetLastError();
+}
+hipError_t launch_film_add(float* dst, const float* src, size_t n_floats, hipStream_t stream) {   // n_floats % 4 == 0 (padded by the caller)
+    const size_t n4 = n_floats / 4;
+    int grid = (int)std::min<size_t>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(film_add_kernel, dim3(grid), dim3(256), 0, stream, dst, src, n4);
     return hipGetLastError();
 }
 hipError_t launch_resolve(const float* d_accum, uint32_t n_values, uint32_t spp, float* d_out, hipStream_t stream) {

@@ -109,7 +109,7 @@ def _ptr(a, ty):
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
     "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_set_bvh_builder", "scene_build", "render", "render_accum_device", "film_resolve_device",
-    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log",
+    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log", "scene_build_multi", "render_multi", "scene_export_bvh",
     "last_error", "version",
 ]
 
@@ -298,6 +298,8 @@ class Product(Backend):
         lib.mi355pt_render_accum_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32,
                                                     C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         lib.mi355pt_film_resolve_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        if not hasattr(lib, "mi355pt_render_sample_log"):      # an older build loaded through MI355PT_LIB for an A/B timing run
+            return
         lib.mi355pt_sample_log_records.argtypes = [C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]
         lib.mi355pt_render_sample_log.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32] + \
             [C.POINTER(C.c_float)] * 3 + [C.c_size_t, C.POINTER(C.c_float)]
@@ -336,6 +338,29 @@ class Product(Backend):
         self.check(self.lib.mi355pt_render_sample_log(scene.h, C.byref(cam), C.byref(params), s_begin, s_end, _ptr(L, C.c_float),
                                                       _ptr(lam, C.c_float), _ptr(pdf, C.c_float), n.value, _ptr(acc, C.c_float)), "render_sample_log")
         return (L, lam, pdf, acc) if want_accum else (L, lam, pdf)
+
+    def export_bvh(self, scene):
+        """mi355pt_scene_export_bvh -> (nodes (n, 16) uint32 view of the 64-B records, tris (m, 12) uint32 view of the 48-B records, root)"""
+        fn = self.lib.mi355pt_scene_export_bvh
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+        nn, nt, root = C.c_uint32(0), C.c_uint32(0), C.c_int32(0)
+        self.check(fn(scene.h, None, C.byref(nn), None, C.byref(nt), C.byref(root)), "scene_export_bvh")
+        nodes = np.zeros((nn.value, 16), np.uint32); tris = np.zeros((nt.value, 12), np.uint32)
+        self.check(fn(scene.h, nodes.ctypes.data, C.byref(nn), tris.ctypes.data, C.byref(nt), C.byref(root)), "scene_export_bvh")
+        return nodes, tris, root.value
+
+    def build_multi(self, scene, cam, device_ids):
+        """mi355pt_scene_build_multi: replicate the (described, not yet built) scene on the listed devices."""
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self.lib.mi355pt_scene_build_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.POINTER(C.c_int)]
+        self.check(self.lib.mi355pt_scene_build_multi(scene.h, C.byref(cam), len(device_ids), ids), "scene_build_multi")
+
+    def render_multi(self, scene, cam, params):
+        """mi355pt_render_multi -> (H, W, 3) float32, the frame mi355pt_render returns, rendered by all devices of the scene."""
+        out = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        self.lib.mi355pt_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.POINTER(C.c_float)]
+        self.check(self.lib.mi355pt_render_multi(scene.h, C.byref(cam), C.byref(params), _ptr(out, C.c_float)), "render_multi")
+        return out
 
     def film_resolve_device(self, d_accum_ptr, n_pixels, spp, d_out_ptr, stream=None):
         self.check(self.lib.mi355pt_film_resolve_device(C.c_void_p(d_accum_ptr), n_pixels, spp, C.c_void_p(d_out_ptr),

@@ -116,8 +116,9 @@ def _mat4_trs_scene17():
     return (T @ (S @ R)).astype(np.float32)
 
 
-def load_scene(scene, scene_id, width, height, tex_size=1024):
-    """load_scene_N(&mut scene, &mut camera) + scene.build(&camera) (main.rs:70-106).  Returns the camera."""
+def load_scene(scene, scene_id, width, height, tex_size=1024, build=True):
+    """load_scene_N(&mut scene, &mut camera) + scene.build(&camera) (main.rs:70-106).  Returns the camera.
+    build=False: describe only (the caller builds, e.g. with Product.build_multi)."""
     p = presets()
     scene.set_rgb2spec(srgb_table())
     if scene_id == 3:      # scene_3.rs:13-31: textured + normal-mapped Lambert hero
@@ -331,5 +332,6 @@ def load_scene(scene, scene_id, width, height, tex_size=1024):
         cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
     else:
         raise ValueError(f"scene {scene_id} is outside the hot-path scope (SURVEY.md §8)")
-    scene.build(cam)
+    if build:
+        scene.build(cam)
     return cam
