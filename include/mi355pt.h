@@ -124,6 +124,11 @@ typedef struct mi355pt_params {
                                         * max(T) >= 1 (base_renderer.rs:76-92); with a slack s the gate is max(T) >= 1 - s.
                                         * Used by the parity tests to show that GPU / oracle path flips on solid constant-eta
                                         * dielectrics come from that gate sitting on T = F * (1 / pdf) = 1 +- 1 ulp */
+    uint32_t albedo_lut;               /* SimpleClearcoatPbrMaterial's coat weight (simple_pbr_clearcoat_material.rs:190-192): 0 = the
+                                        * reference's 64-sample Monte-Carlo directional albedo per shading vertex
+                                        * (generalized_schlick.rs:893-918, counter RNG); 1 = its expectation E(cos theta) from a 64-entry
+                                        * table per material (mi355pt_coat_albedo_table), deterministic and faster: an OPTION that deviates
+                                        * from the reference's estimator by less than that estimator's own noise */
 } mi355pt_params;
 
 typedef struct mi355pt_stats {
@@ -168,6 +173,12 @@ int mi355pt_scene_add_delta_light(mi355pt_scene* s, const mi355pt_light_desc* de
  * presets::cie_illum_d6500() (rgb_illuminant_spectrum.rs:28).  Only the rotation of the transform matters. */
 int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const float* rgb, uint32_t width, uint32_t height,
                                         const float local_to_world[16], uint32_t illuminant_lut);
+/* The table behind mi355pt_params.albedo_lut (host-only, deterministic; no reference counterpart): out[k], k < 64, is the expectation
+ * of GeneralizedSchlickBsdf::directional_albedo's estimator f |cos i| / pdf (generalized_schlick.rs:893-918; mode R, scalar r0, r90 = 1)
+ * at cos(theta_o) = (k + 0.5) / 64, integrated over a 256 x 256 midpoint grid of the (u, v) square in double precision.  The kernel
+ * (and the oracle in its LUT mode) interpolate it linearly in |cos(theta_o)|.  mi355pt_scene_build computes it for every clearcoat
+ * material. */
+int mi355pt_coat_albedo_table(float alpha, float r0, float out[64]);
 /* Which builder mi355pt_scene_build uses for the BVH (stands where Bvh::build is, scene/src/bvh.rs:92-230; no reference
  * counterpart for the choice).  AUTO: host sweep SAH below 131 072 triangles, the GPU binned-SAH builder from there on;
  * HOST / GPU force one (GPU fails with MI355PT_E_DEVICE rather than substituting the host builder).  The environment

@@ -463,6 +463,7 @@ struct Clearcoat {
     const Material& m; SS base_color, tint; uint64_t key;
     float metallic, roughness;     // FloatParameter values at the shading point
     float thickness;
+    int draws_mode = 0;            // Scene::cc_draws: 0 one estimate per vertex shared by sample / evaluate / pdf, 1 three independent ones, 2 table
     static float r2a(float r) { return r * r; }                                            // :76-78
     static float diel_r0(float ior) { float r = (ior - 1.0f) / (ior + 1.0f); return r * r; }   // :81-84
     static SS attenuation(SS tint, float thickness, float cos_theta) {                     // :88-107
@@ -518,7 +519,21 @@ struct Clearcoat {
         if (metallic <= 0.0f) return pdf_dielectric(wo, wi);
         return metal(SS::one()).pdf_R(wo, wi) * metallic + pdf_dielectric(wo, wi) * (1.0f - metallic);
     }
-    float coat_weight(V3 wo) const { return coat().directional_albedo(wo, key).average(); }                             // :190-192
+    // The coat weight (:190-192, 318-320, 416-418).  `which`: 0 sample, 1 evaluate, 2 pdf.  The reference draws a fresh 64-sample estimate from the
+    // thread RNG in each of the three; the product (and this oracle by default) share ONE estimate per vertex.  draws_mode 1 keys
+    // the three calls differently — three independent estimates, the reference's structure — so that the deviation can be measured
+    // (tools/clearcoat_modes.py); draws_mode 2 reads the estimate's expectation from the material's table (mi355pt_params.albedo_lut).
+    float coat_weight(V3 wo, int which) const {
+        if (draws_mode == 2 && !m.cc_albedo_lut.empty()) {
+            const float* tab = m.cc_albedo_lut.data();
+            const float x = std::fmin(std::fmax(std::fabs(wo.z) * 64.0f - 0.5f, 0.0f), 63.0f);
+            const int i0 = std::min((int)x, 62);
+            const float tt = std::fmin(x - (float)i0, 1.0f);
+            return tab[i0] + (tab[i0 + 1] - tab[i0]) * tt;
+        }
+        const uint64_t k = draws_mode == 1 ? key ^ (0x9E3779B97F4A7C15ull * (uint64_t)which) : key;
+        return coat().directional_albedo(wo, k).average();
+    }
 };
 
 inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, Wavelengths& wl, V3 wo, const ShadingPoint& sp) const {
@@ -526,7 +541,7 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
     if (m.type == MAT_CLEARCOAT) {                                           // simple_pbr_clearcoat_material.rs:137-260
         Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
                      scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv),
-                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv)};
+                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv), scene.cc_draws};
         M4 tf = normal_map_transform(m, sp.uv);
         M4 tf_inv = inverse(tf);
         V3 wo_nm = transform_vector3(tf, wo);
@@ -536,7 +551,7 @@ inline MaterialSample MaterialEval::sample(const Material& m, float uc, V2 uv, W
             ms.f = bs.f; ms.wi = transform_vector3(tf_inv, bs.wi); ms.pdf = bs.pdf; ms.sample_type = bs.type; ms.is_sampled = true;
             return ms;
         }
-        float fc = cc.coat_weight(wo_nm);
+        float fc = cc.coat_weight(wo_nm, 0);
         if (uc < fc) {
             if (!cc.coat().sample_R(wo_nm, uv, &bs)) return ms;
             ms.f = bs.f; ms.wi = transform_vector3(tf_inv, bs.wi); ms.pdf = bs.pdf * fc; ms.sample_type = bs.type; ms.is_sampled = true;
@@ -600,11 +615,11 @@ inline SS MaterialEval::evaluate(const Material& m, const Wavelengths& wl, V3 wo
     if (m.type == MAT_CLEARCOAT) {                                           // :261-341
         Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
                      scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv),
-                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv)};
+                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv), scene.cc_draws};
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
         if (cc.thickness <= 0.0f) return cc.eval_base(wo_nm, wi_nm);
-        float fc = cc.coat_weight(wo_nm);
+        float fc = cc.coat_weight(wo_nm, 1);
         SS cf = cc.coat().evaluate_R(wo_nm, wi_nm);
         SS sf = cc.eval_base(wo_nm, wi_nm);
         SS att = Clearcoat::attenuation(cc.tint, cc.thickness, wo_nm.z) * Clearcoat::attenuation(cc.tint, cc.thickness, wi_nm.z);
@@ -644,11 +659,11 @@ inline float MaterialEval::pdf(const Material& m, const Wavelengths& wl, V3 wo, 
     if (m.type == MAT_CLEARCOAT) {                                           // :342-433
         Clearcoat cc{m, scene.sample_spectrum_param(m.color, sp.uv, wl, ctr), scene.sample_spectrum_param(m.cc_tint, sp.uv, wl, ctr), mc_key,
                      scene.sample_float_param(m.cc_metallic, m.metallic_tex, sp.uv), scene.sample_float_param(m.roughness, m.roughness_tex, sp.uv),
-                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv)};
+                     scene.sample_float_param(m.cc_thickness, m.cc_thickness_tex, sp.uv), scene.cc_draws};
         M4 tf = normal_map_transform(m, sp.uv);
         V3 wo_nm = transform_vector3(tf, wo), wi_nm = transform_vector3(tf, wi);
         if (cc.thickness <= 0.0f) return cc.pdf_base(wo_nm, wi_nm);
-        float fc = cc.coat_weight(wo_nm);
+        float fc = cc.coat_weight(wo_nm, 2);
         return cc.coat().pdf_R(wo_nm, wi_nm) * fc + cc.pdf_base(wo_nm, wi_nm) * (1.0f - fc);
     }
     if (m.type == MAT_METAL) {                                               // metal_material.rs:194-229

@@ -34,6 +34,7 @@ struct Material {
     // clearcoat (simple_pbr_clearcoat_material.rs): filled by the API when type == MAT_CLEARCOAT
     float cc_metallic = 0, cc_base_ior = 1.5f, cc_ior = 1.5f, cc_roughness = 0, cc_thickness = 0;
     SpectrumParameter cc_tint;
+    std::vector<float> cc_albedo_lut;   // 64 entries: the coat's E(cos theta) table (Scene::cc_draws == 2), handed over by the test
     bool is_emissive() const { return type == MAT_EMISSIVE; }
 };
 
@@ -318,6 +319,7 @@ struct Scene {
     // of transforming the ray into each primitive's local space (primitive/impls/triangle_mesh.rs:89-119).  Mathematically the same hit;
     // numerically it rounds like the product's flat render-space BVH, which lets a test attribute GPU-vs-oracle path flips to the lowering.
     bool render_space_lowering = false;
+    int cc_draws = 0;                             // clearcoat coat-weight mode, see Clearcoat::coat_weight (o_materials.hpp)
     bool built = false;
 
     // EmissiveTriangleMesh::new (emissive_triangle_mesh.rs:28-68)

@@ -55,6 +55,14 @@ extern "C" {
 int ptoracle_scene_create(ptoracle_scene** out) { *out = new ptoracle_scene(); return 0; }
 void ptoracle_scene_destroy(ptoracle_scene* s) { delete s; }
 int ptoracle_scene_set_faithful(ptoracle_scene* s, int faithful) { s->scene.faithful = faithful != 0; return 0; }
+// clearcoat coat-weight mode (Clearcoat::coat_weight): 0 shared estimate per vertex (default, = the product), 1 three independent estimates
+// (the reference's structure), 2 table lookup; the table of material `mat` (64 floats, mi355pt_coat_albedo_table) for mode 2
+int ptoracle_scene_set_clearcoat_mode(ptoracle_scene* s, int mode) { s->scene.cc_draws = mode; return 0; }
+int ptoracle_scene_set_coat_albedo_lut(ptoracle_scene* s, uint32_t mat, const float* table64) {
+    if (mat >= s->scene.materials.size()) return -1;
+    s->scene.materials[mat].cc_albedo_lut.assign(table64, table64 + 64);
+    return 0;
+}
 // diagnostic, call before scene_build: 1 = pre-transformed render-space triangles (the product's lowering) instead of the reference's
 // per-primitive ray transform (o_scene.hpp Scene::render_space_lowering)
 int ptoracle_scene_set_lowering(ptoracle_scene* s, int render_space) { s->scene.render_space_lowering = render_space != 0; return 0; }

@@ -49,6 +49,20 @@ class Oracle(ffi.Backend):
     def set_faithful(self, scene, faithful):
         self.lib.ptoracle_scene_set_faithful(scene.h, 1 if faithful else 0)
 
+    def set_clearcoat_mode(self, scene, mode, product=None):
+        """Coat-weight mode of SimpleClearcoatPbrMaterial: "shared" (one 64-sample estimate per vertex, = the product's default),
+        "independent" (three estimates per vertex: the reference's structure) or "lut" (the expectation from the 64-entry table of
+        mi355pt_params.albedo_lut; `product` supplies the tables through mi355pt_coat_albedo_table for every clearcoat material)."""
+        self.lib.ptoracle_scene_set_clearcoat_mode.argtypes = [C.c_void_p, C.c_int]
+        self.lib.ptoracle_scene_set_clearcoat_mode(scene.h, {"shared": 0, "independent": 1, "lut": 2}[mode])
+        if mode == "lut":
+            self.lib.ptoracle_scene_set_coat_albedo_lut.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+            for mat_id, desc in enumerate(scene.material_descs):
+                if desc.type == ffi.MAT_CLEARCOAT:
+                    r = (desc.clearcoat_ior - 1.0) / (desc.clearcoat_ior + 1.0)
+                    tab = product.coat_albedo_table(np.float32(desc.clearcoat_roughness) * np.float32(desc.clearcoat_roughness), np.float32(r) * np.float32(r))
+                    assert self.lib.ptoracle_scene_set_coat_albedo_lut(scene.h, mat_id, ffi._ptr(tab, C.c_float)) == 0
+
     def set_render_space_lowering(self, scene, on=True):
         """Diagnostic, BEFORE the scene is built (load_scene builds): the product's instance lowering instead of the reference's."""
         self.lib.ptoracle_scene_set_lowering.argtypes = [C.c_void_p, C.c_int]

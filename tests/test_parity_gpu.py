@@ -169,6 +169,29 @@ def test_frames_match_the_oracle_sample_for_sample(product, oracle, pkg, scene_i
     assert rmse <= lim_rmse and off <= lim_off, (rmse, off)
 
 
+@pytest.mark.parametrize("scene_id,strategy", [(17, "nee"), (17, "mis"), (16, "mis"), (18, "nee"), (19, "mis")])
+def test_albedo_lut_frames_match_the_oracle(product, oracle, pkg, scene_id, strategy):
+    """mi355pt_params.albedo_lut (SURVEY Appendix A, Q13's option): the coat weight of SimpleClearcoatPbrMaterial from the 64-entry E(cos theta)
+    table of its material instead of the 64-sample estimate.  GPU and oracle read the same table (mi355pt_coat_albedo_table) with the
+    same interpolation, so they trace the same paths: the sample-for-sample frame bar.  The option changes the picture by less than the
+    estimator's own noise (tools/clearcoat_modes.py, profiles/r02_clearcoat_modes.jsonl)."""
+    pair = {}
+    for name, be in (("gpu", product), ("cpu", oracle)):
+        sc = be.new_scene()
+        pair[name] = (sc, pkg.scenes.load_scene(sc, scene_id, 64, 48, tex_size=128))
+    oracle.set_faithful(pair["cpu"][0], False)
+    oracle.set_clearcoat_mode(pair["cpu"][0], "lut", product)
+    prm = pkg.make_params(64, strategy, "sobol", albedo_lut=1, rr_gate_slack=1e-5 if scene_id in KNIFE_EDGE_SCENES else 0.0)
+    g = product.render(pair["gpu"][0], pair["gpu"][1], prm)
+    c = oracle.render(pair["cpu"][0], pair["cpu"][1], prm)
+    rmse = float(np.sqrt(np.mean((g - c) ** 2)))
+    off = int((np.abs(g - c).max(axis=2) > 0.01).sum())
+    assert rmse <= 5e-4 and off <= 6, (rmse, off)
+    # and the option is an option: the default (64-sample estimate) gives another, equally noisy, frame of the same scene
+    d = product.render(pair["gpu"][0], pair["gpu"][1], pkg.make_params(64, strategy, "sobol"))
+    assert not np.array_equal(d, g) and abs(float(d.mean()) - float(g.mean())) <= 0.01 * float(g.mean())
+
+
 @pytest.mark.parametrize("scene_id", [9, 13])
 def test_solid_plastic_flips_are_the_roulette_gate(product, oracle, pkg, scene_id):
     """Root cause of the round-1 'open divergence' on the solid plastic heroes (scene_9.rs, scene_13.rs): a specular REFLECTION off a

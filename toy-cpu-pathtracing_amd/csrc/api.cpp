@@ -142,6 +142,7 @@ DevParams make_params(const mi355pt_camera* cam, const mi355pt_params* p, uint32
     d.spp = p->spp; d.seed = p->seed; d.max_depth = p->max_depth; d.strategy = p->strategy; d.sampler = p->sampler;
     d.exposure = p->exposure;
     d.rr_gate = 1.0f - p->rr_gate_slack;
+    d.albedo_lut = p->albedo_lut ? 1u : 0u;
     d.log2_spp = log2_int(p->spp);                                              // ZSobolSampler::new (:179-196)
     uint32_t res = round_up_pow2(std::max(cam->width, cam->height));
     d.n_base4_digits = log2_int(res) + (d.log2_spp + 1) / 2;
@@ -364,6 +365,11 @@ int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, co
     if (geom >= s->impl.meshes.size() || mat >= s->impl.materials.size()) return fail(MI355PT_E_INVALID, "bad geometry/material id");
     HostInstance hi; hi.geom = geom; hi.mat = mat; std::memcpy(hi.l2w, l2w, sizeof(float) * 16);
     s->impl.instances.push_back(hi);
+    return MI355PT_OK;
+}
+int mi355pt_coat_albedo_table(float alpha, float r0, float* out) {
+    if (!out || !(alpha >= 0.0f) || !(r0 >= 0.0f)) return fail(MI355PT_E_INVALID, "bad argument");
+    coat_albedo_table(alpha, r0, out);
     return MI355PT_OK;
 }
 int mi355pt_scene_set_bvh_builder(mi355pt_scene* s, int mode) {

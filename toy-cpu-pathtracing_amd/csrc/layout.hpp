@@ -23,7 +23,10 @@
 
 namespace pt {
 
-constexpr int STACK_DEPTH = 24;        // per-lane traversal stack entries kept in LDS (6 KB per wave)
+#ifndef PT_STACK_DEPTH
+#define PT_STACK_DEPTH 24
+#endif
+constexpr int STACK_DEPTH = PT_STACK_DEPTH;        // per-lane traversal stack entries kept in LDS (6 KB per wave)
 constexpr int MAX_LEAF_TRIS = 4;
 constexpr int MAX_BUILD_DEPTH = 22;    // builder guarantees depth <= this (< STACK_DEPTH)
 constexpr int HASH_TABLE_DIMS = 136;   // precomputed murmur(dimension, seed) entries: 3 + 16 bounces x 8 draws
@@ -94,7 +97,7 @@ struct alignas(16) DevMaterial {
     DevSpectrum cc_tint;   // clearcoat tint; metal: extinction coefficient k
     uint32_t metallic_tex, roughness_tex;   // FloatParameter::Texture ids (red channel), ~0 = use the constants above
     uint32_t cc_thickness_tex;
-    uint32_t pad1;
+    uint32_t cc_albedo_lut;   // clearcoat: first entry of this material's 64-entry coat-albedo table in DevScene::cc_albedo
 };
 static_assert(sizeof(DevMaterial) == 160, "material record");
 
@@ -155,6 +158,7 @@ struct DevScene {
     const float* z_nodes;         // [64]
     const uint32_t* texels;       // RGBA8 pool
     const DevTexture* textures;
+    const float* cc_albedo;       // [n clearcoat materials][64] E(cos theta) of the coat's directional albedo (mi355pt_params.albedo_lut)
     uint32_t n_nodes, n_tris, n_lights, n_materials;
     int32_t root;                 // root link (node index, or leaf if the scene has <= MAX_LEAF_TRIS tris)
     uint32_t pad[3];
@@ -181,6 +185,7 @@ struct DevParams {
     uint32_t sample_prefix_digits;          // single-pixel items (b = 0) over aligned 4^m sample blocks: this many top base-4 digits of the
                                             // sample index are item-uniform too and join the Sobol prefix tables
     uint32_t stats_mode;                    // instrumented variant only: 1 = reference traversal order (canonical counts), 2 = production traversal
+    uint32_t albedo_lut;                    // clearcoat coat weight from the per-material table instead of the 64-sample estimate
     float rr_gate;                          // Russian roulette is skipped when max(T) >= rr_gate (1 = the reference; mi355pt_params.rr_gate_slack)
     float xyz_to_rgb[9];                    // row-major sRGB matrix (gamut.rs:50-63)
 };

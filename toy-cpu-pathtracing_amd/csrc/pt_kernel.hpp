@@ -10,8 +10,10 @@
 
 namespace pt {
 
-#ifndef PT_MIN_WAVES
+#ifndef PT_MIN_WAVES_CC
 #define PT_MIN_WAVES_CC 3
+#endif
+#ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4   // 128 VGPRs: measured +26 % over the unconstrained 220-VGPR build (latency hiding beats the spills)
 #endif
 // work item -> lane assignment
@@ -61,7 +63,10 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                                                 float* __restrict__ accum, float* __restrict__ partial, unsigned* __restrict__ work_counter,
                                                 DevStats* __restrict__ stats, PathOut pout) {
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
-    __shared__ float s_film[64 * 3];                 // the work item's 8x8 film tile
+#ifndef PT_FILM_PIX
+#define PT_FILM_PIX 64
+#endif
+    __shared__ float s_film[PT_FILM_PIX * 3];                 // the work item's 8x8 film tile
     __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
     __shared__ uint32_t s_p6[SOBOL_HI_DIMS];
     __shared__ unsigned s_work;
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         // The work item's paths form a pool of (pixel, sample) pairs, sample-major.  A lane whose path ended takes the next pair,
         // whichever pixel of the tile it belongs to: no lane idles while another still has samples of "its" pixel to do.  The
         // tile's film lives in LDS (ds_add_f32); the hand-out order is a function of the wave's own deterministic schedule.
-        s_film[3 * lane] = 0.0f; s_film[3 * lane + 1] = 0.0f; s_film[3 * lane + 2] = 0.0f;
+        if (lane < PT_FILM_PIX) { s_film[3 * lane] = 0.0f; s_film[3 * lane + 1] = 0.0f; s_film[3 * lane + 2] = 0.0f; }
         __syncthreads();
         const uint32_t n_s = job0.s_end > job0.s_cur ? job0.s_end - job0.s_cur : 0u;
         const uint32_t pool_size = n_s << (2u * blk_log2);
@@ -164,7 +169,9 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
                 if (active) end_path = shade_vertex_head<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, C);
                 // the coat's 64-sample directional albedo, estimated by the whole wave for the lanes that need it
-                C.cc_fc = coat_directional_albedo_coop(active && C.cont && C.need_cc, C.cc_alpha_c, C.cc_r0c, C.wo_nm, C.mc_key, lane);
+                const bool want_mc = active && C.cont && C.need_cc;
+                const float fc_mc = coat_directional_albedo_coop(want_mc, C.cc_alpha_c, C.cc_r0c, C.wo_nm, C.mc_key, lane);
+                if (want_mc) C.cc_fc = fc_mc;
                 if (active && C.cont) end_path = shade_vertex_tail<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
             } else {
                 if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);

@@ -414,6 +414,14 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                 // sharing one estimate per vertex keeps every marginal identical and is 3x cheaper.
                 C.mc_key = mix_bits(((uint64_t)smp.morton << 32) | (uint64_t)smp.dimension) ^ 0xD1B54A32D192ED03ull;
                 C.need_cc = thick > 0.0f;
+                if (prm.albedo_lut != 0u && thick > 0.0f) {                     // the estimate's expectation from the material's table (an option, see mi355pt.h)
+                    const float* tab = sc.cc_albedo + mat->cc_albedo_lut;
+                    const float x = fminf(fmaxf(fabsf(wo_nm.z) * 64.0f - 0.5f, 0.0f), 63.0f);
+                    const int i0 = min((int)x, 62);
+                    const float tt = fminf(x - (float)i0, 1.0f);
+                    C.cc_fc = tab[i0] + (tab[i0 + 1] - tab[i0]) * tt;
+                    C.need_cc = false;
+                }
             }
         }
     }

@@ -103,6 +103,56 @@ bool SceneImpl::table_lookup_srgb(const float enc[3], float c[3], bool linear) c
     return true;
 }
 
+// Expectation of GeneralizedSchlickBsdf::directional_albedo's estimator (generalized_schlick.rs:893-918) for ScatterMode::R, a scalar r0,
+// r90 = 1, exponent 5, tint 1 and alpha_x = alpha_y = alpha: mean over (u, v) in [0,1)^2 of f |cos i| / pdf with wi drawn by the GGX
+// visible-normal sampler (:165-199) — the quantity the reference estimates with 64 random points per call.  Double precision, 256 x 256
+// midpoints: deterministic, error ~1e-5 (the 64-point estimate it replaces has a standard deviation of 1e-2 .. 1e-1).
+void coat_albedo_table(float alpha_f, float r0_f, float out[64]) {
+    const double a = alpha_f, r0 = r0_f, PI = 3.14159265358979323846;
+    auto lambda = [&](double x, double y, double z) { double c2 = z * z; if (c2 == 0.0) return 0.0; return (std::sqrt(1.0 + a * a * (x * x + y * y) / c2) - 1.0) / 2.0; };
+    auto D = [&](double x, double y, double z) { double c2 = z * z; if (c2 == 0.0) return 0.0; double e = (x * x + y * y) / c2 / (a * a); return 1.0 / (PI * a * a * c2 * c2 * (1.0 + e) * (1.0 + e)); };
+    for (int k = 0; k < 64; ++k) {
+        const double cz = (k + 0.5) / 64.0, sx = std::sqrt(std::max(1.0 - cz * cz, 0.0));     // wo = (sin, 0, cos): the estimate is isotropic in wo
+        const double wo[3] = {sx, 0.0, cz};
+        double sum = 0.0;
+        const int N = 256;
+        for (int iu = 0; iu < N; ++iu) for (int iv = 0; iv < N; ++iv) {
+            const double u = (iu + 0.5) / N, v = (iv + 0.5) / N;
+            double term = 0.0;
+            if (a < 1e-3) {                                                     // effectively smooth: wi = mirror, f = F, pdf = 1 (:232-251)
+                double o = 1.0 - std::min(std::max(cz, 0.0), 1.0);
+                term = (r0 + (1.0 - r0) * o * o * o * o * o) * cz;
+            } else {
+                double wh[3] = {a * wo[0], a * wo[1], wo[2]};
+                double l = std::sqrt(wh[0] * wh[0] + wh[1] * wh[1] + wh[2] * wh[2]); wh[0] /= l; wh[1] /= l; wh[2] /= l;
+                double t1[3] = {1, 0, 0};
+                if (wh[2] < 0.99999) { double tl = std::sqrt(wh[0] * wh[0] + wh[1] * wh[1]); t1[0] = -wh[1] / tl; t1[1] = wh[0] / tl; t1[2] = 0.0; }
+                const double t2[3] = {wh[1] * t1[2] - wh[2] * t1[1], wh[2] * t1[0] - wh[0] * t1[2], wh[0] * t1[1] - wh[1] * t1[0]};
+                const double r = std::sqrt(u), th = 2.0 * PI * v;
+                const double px = r * std::cos(th), pyy = r * std::sin(th);
+                const double h = std::sqrt(std::max(1.0 - px * px, 0.0)), lf = (1.0 + wh[2]) / 2.0;
+                const double py = h * (1.0 - lf) + pyy * lf, pz = std::sqrt(std::max(1.0 - px * px - py * py, 0.0));
+                double nh[3] = {t1[0] * px + t2[0] * py + wh[0] * pz, t1[1] * px + t2[1] * py + wh[1] * pz, t1[2] * px + t2[2] * py + wh[2] * pz};
+                double wm[3] = {a * nh[0], a * nh[1], std::max(1e-6, nh[2])};
+                l = std::sqrt(wm[0] * wm[0] + wm[1] * wm[1] + wm[2] * wm[2]); wm[0] /= l; wm[1] /= l; wm[2] /= l;
+                const double wodm = wo[0] * wm[0] + wo[1] * wm[1] + wo[2] * wm[2];
+                const double wi[3] = {2.0 * wodm * wm[0] - wo[0], 2.0 * wodm * wm[1] - wo[1], 2.0 * wodm * wm[2] - wo[2]};
+                const double cd = std::fabs(wodm), ci = std::fabs(wi[2]);
+                if (wo[2] * wi[2] > 0.0 && cd >= 1e-6 && ci > 0.0) {
+                    const double d = D(wm[0], wm[1], wm[2]);
+                    const double pdf = (1.0 / (1.0 + lambda(wo[0], wo[1], wo[2]))) / cz * d * cd / (4.0 * cd);
+                    const double g = 1.0 / (1.0 + lambda(wo[0], wo[1], wo[2]) + lambda(wi[0], wi[1], wi[2]));
+                    const double o = 1.0 - std::min(std::max(cd, 0.0), 1.0);
+                    const double f = (r0 + (1.0 - r0) * o * o * o * o * o) * d * g / (4.0 * cz);
+                    if (pdf > 0.0) term = f * ci / pdf;
+                }
+            }
+            sum += term;
+        }
+        out[k] = (float)(sum / ((double)N * N));
+    }
+}
+
 int SceneImpl::lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, bool allow_texture, std::string* err) const {
     std::memset(out, 0, sizeof(*out));
     switch (in.kind) {
@@ -390,7 +440,21 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     if ((rc = upload(this, tris, &dev.tris, err))) return rc;
     if ((rc = upload(this, shade, &dev.shade, err))) return rc;
     if ((rc = upload(this, dinst, &dev.instances, err))) return rc;
-    if ((rc = upload(this, materials, &dev.materials, err))) return rc;
+    {   // per clearcoat material: the coat's directional-albedo table (mi355pt_params.albedo_lut); the device copy of the material names its offset
+        std::vector<float> cc_tab;
+        std::vector<DevMaterial> mats = materials;
+        for (DevMaterial& m : mats) {
+            m.cc_albedo_lut = 0;
+            if (m.type != MT_CLEARCOAT) continue;
+            float r = (m.cc_ior - 1.0f) / (m.cc_ior + 1.0f);
+            m.cc_albedo_lut = (uint32_t)cc_tab.size();
+            cc_tab.resize(cc_tab.size() + 64);
+            coat_albedo_table(m.cc_roughness * m.cc_roughness, r * r, cc_tab.data() + m.cc_albedo_lut);
+        }
+        if (cc_tab.empty()) cc_tab.assign(64, 0.0f);
+        if ((rc = upload(this, cc_tab, &dev.cc_albedo, err))) return rc;
+        if ((rc = upload(this, mats, &dev.materials, err))) return rc;
+    }
     if ((rc = upload(this, lights, &dev.lights, err))) return rc;
     if ((rc = upload(this, light_tris, &dev.light_tris, err))) return rc;
     if ((rc = upload(this, lut_pool, &dev.luts, err))) return rc;

@@ -75,6 +75,9 @@ struct SceneImpl {
     int build(const mi355pt_camera* cam, const float* cmf_xyz /*3*470*/, std::string* err);
 };
 
+// mi355pt_coat_albedo_table (scene.cpp): E(cos theta_o) of the clearcoat's directional-albedo estimator, 64 entries
+void coat_albedo_table(float alpha, float r0, float out[64]);
+
 // baked CIE 1931 colour matching functions shipped with the library (data/presets470.bin rows cie_x/y/z)
 const float* builtin_cmf_xyz();   // 3*470 floats or nullptr if not loaded
 bool load_builtin_cmf(std::string* err);

@@ -76,7 +76,7 @@ class Camera(C.Structure):
 class Params(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("seed", C.c_uint32), ("max_depth", C.c_uint32), ("strategy", C.c_uint32),
                 ("sampler", C.c_uint32), ("exposure", C.c_float), ("shard_index", C.c_uint32),
-                ("shard_count", C.c_uint32), ("collect_stats", C.c_uint32), ("rr_gate_slack", C.c_float)]
+                ("shard_count", C.c_uint32), ("collect_stats", C.c_uint32), ("rr_gate_slack", C.c_float), ("albedo_lut", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -97,8 +97,9 @@ def make_camera(position, direction, up, width, height, fov_deg=45.0):
 
 
 def make_params(spp, strategy="mis", sampler="sobol", seed=0, max_depth=16, exposure=1.0, shard_index=0, shard_count=1,
-                collect_stats=0, rr_gate_slack=0.0):
-    return Params(spp, seed, max_depth, STRATEGY[strategy], SAMPLER[sampler], exposure, shard_index, shard_count, collect_stats, rr_gate_slack)
+                collect_stats=0, rr_gate_slack=0.0, albedo_lut=0):
+    return Params(spp, seed, max_depth, STRATEGY[strategy], SAMPLER[sampler], exposure, shard_index, shard_count, collect_stats, rr_gate_slack,
+                  albedo_lut)
 
 
 def _ptr(a, ty):
@@ -109,7 +110,7 @@ def _ptr(a, ty):
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
     "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_set_bvh_builder", "scene_build", "render", "render_accum_device", "film_resolve_device",
-    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log", "scene_build_multi", "render_multi", "scene_export_bvh",
+    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log", "scene_build_multi", "render_multi", "scene_export_bvh", "coat_albedo_table",
     "last_error", "version",
 ]
 
@@ -178,6 +179,7 @@ class SceneHandle:
         self.h = C.c_void_p()
         backend.check(backend.fn("scene_create")(C.byref(self.h)), "scene_create")
         self.keep = []
+        self.material_descs = []       # by material id (delta / environment lights add hidden materials on the library side, after these)
 
     def close(self):
         if self.h:
@@ -224,6 +226,9 @@ class SceneHandle:
     def add_material(self, desc):
         out = C.c_uint32()
         self.b.check(self.b.fn("scene_add_material")(self.h, C.byref(desc), C.byref(out)), "scene_add_material")
+        while len(self.material_descs) <= out.value:
+            self.material_descs.append(None)
+        self.material_descs[out.value] = desc
         return out.value
 
     def add_instance(self, geom, mat, local_to_world=None):
@@ -300,6 +305,8 @@ class Product(Backend):
         lib.mi355pt_film_resolve_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         if not hasattr(lib, "mi355pt_render_sample_log"):      # an older build loaded through MI355PT_LIB for an A/B timing run
             return
+        if not hasattr(lib, "mi355pt_render_sample_log"):      # an older build loaded through MI355PT_LIB for an A/B timing run
+            return
         lib.mi355pt_sample_log_records.argtypes = [C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]
         lib.mi355pt_render_sample_log.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32] + \
             [C.POINTER(C.c_float)] * 3 + [C.c_size_t, C.POINTER(C.c_float)]
@@ -348,6 +355,13 @@ class Product(Backend):
         nodes = np.zeros((nn.value, 16), np.uint32); tris = np.zeros((nt.value, 12), np.uint32)
         self.check(fn(scene.h, nodes.ctypes.data, C.byref(nn), tris.ctypes.data, C.byref(nt), C.byref(root)), "scene_export_bvh")
         return nodes, tris, root.value
+
+    def coat_albedo_table(self, alpha, r0):
+        """mi355pt_coat_albedo_table: the 64-entry E(cos theta) table behind params.albedo_lut (host-only)."""
+        out = np.zeros(64, np.float32)
+        self.lib.mi355pt_coat_albedo_table.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
+        self.check(self.lib.mi355pt_coat_albedo_table(alpha, r0, _ptr(out, C.c_float)), "coat_albedo_table")
+        return out
 
     def build_multi(self, scene, cam, device_ids):
         """mi355pt_scene_build_multi: replicate the (described, not yet built) scene on the listed devices."""
