@@ -146,7 +146,8 @@ KNIFE_EDGE_SCENES = (9, 13, 19)   # solid constant-eta plastic: compared with th
                                                (5, "nee"), (6, "mis"), (7, "mis"), (7, "nee"), (8, "mis"), (9, "mis"), (10, "mis"), (11, "nee"),
                                                (12, "mis"), (13, "mis"), (14, "nee"), (15, "mis"), (16, "mis"), (17, "nee"), (17, "mis"), (18, "nee"),
                                                (19, "mis"), (19, "pt"), (19, "nee"), (20, "mis"), (20, "pt"), (21, "mis"), (21, "nee"), (22, "mis"),
-                                               (22, "nee"), (27, "mis"), (27, "nee"), (27, "pt")])
+                                               (22, "nee"), (27, "mis"), (27, "nee"), (27, "pt"),
+                                               (29, "pt"), (29, "nee"), (29, "mis"), (30, "pt"), (30, "nee"), (30, "mis")])
 def test_frames_match_the_oracle_sample_for_sample(product, oracle, pkg, scene_id, strategy):
     """Every scene id of the radiance test, through the scene's own kernel specialisation (= what bench.py runs for it).  Outside rough
     refraction nothing amplifies a last-bit difference, so GPU and oracle must trace the SAME paths for all but a handful of samples:
@@ -243,6 +244,19 @@ def test_gpu_pt_nee_mis_consistency(product, pkg, scene_id):
     assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
 
 
+def test_gpu_pt_nee_mis_consistency_textured_emitter(product, pkg):
+    """The reference's estimator-consistency criterion on the textured emitter of scene 30: PT sees the panel's radiance at the HIT uv, NEE
+    and MIS sample a point on it and look the radiance up THERE, weighting the light by its value at uv (0.5, 0.5) — three code paths
+    that must converge to one picture."""
+    sc = product.new_scene()
+    cam = pkg.scenes.load_scene(sc, 30, 200, 150, tex_size=256)
+    # (32768 spp: unidirectional PT finds the 1.8 x 1.8 panel by chance only; 0.0146 at 8192 spp is its noise — the oracle's LINEAR channel
+    # means of the three strategies agree within 1 %)
+    imgs = {s: median3(product.quantize_u8(product.render(sc, cam, pkg.make_params(32768, s, "random")))) for s in ("pt", "nee", "mis")}
+    assert gamma22_rmse_u8(imgs["pt"], imgs["nee"]) <= 0.013
+    assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
+
+
 def test_gpu_pt_nee_mis_consistency_metal(product, pkg):
     """The same estimator-consistency criterion on the four rough-gold heroes of scene 7 (ConductorBsdf sample / evaluate /
     pdf must agree for PT, NEE and MIS to converge to one image)."""
@@ -258,7 +272,8 @@ def test_gpu_pt_nee_mis_consistency_metal(product, pkg):
                                                (6, "mis"), (7, "mis"), (7, "nee"), (20, "mis"), (20, "pt"),
                                                (1, "nee"), (2, "mis"), (21, "mis"), (21, "nee"), (19, "mis"), (19, "pt"), (19, "nee"), (22, "mis"), (22, "nee"),
                                                (4, "mis"), (5, "nee"), (9, "mis"), (12, "mis"), (13, "mis"), (14, "nee"), (15, "mis"), (16, "mis"), (18, "nee"),
-                                               (27, "mis"), (27, "nee"), (27, "pt")])
+                                               (27, "mis"), (27, "nee"), (27, "pt"),
+                                               (29, "mis"), (29, "pt"), (30, "mis"), (30, "nee")])
 def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     """Glass (scene 8: dispersive, wavelength termination), thin plastic (scene 10), plain Lambert (scene 0), rough clearcoat
     over rough metal (scene 17), rough SF11 glass (scene 11: microfacet reflection/transmission + light connection), smooth
@@ -268,7 +283,9 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     textured base colour and a normal map (scenes 15 and 22), and the remaining Cornell scenes of the reference: 4 / 5 (other
     texture set, normal map only), 9 / 13 (plastic without thin film, linear-sRGB colour), 12 / 14 (four rough BK7 glass / coloured
     rough plastic heroes), 16 / 18 (near-smooth coat, FloatTexture coat thickness); glass and plastic with a FloatTexture roughness
-    that switches between the specular and the microfacet branch across the surface (scene 27, not a reference scene)."""
+    that switches between the specular and the microfacet branch across the surface (scene 27, not a reference scene); TWO environment
+    lights whose radiance and MIS pdfs are summed (scene 29, scene.rs:185-231, mis_renderer.rs:205-214) and a textured emitter whose
+    radiance is looked up at the hit / sampled uv and whose light-pick weight at uv (0.5, 0.5) (scene 30, emissive_material.rs:48-79)."""
     pair = {}
     for name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()

@@ -298,7 +298,8 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
             if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, err);
             break;
         case MI355PT_MAT_EMISSIVE:
-            if ((rc = im.lower_spectrum(d->color, &m.color, false, &err))) return fail(rc, "emissive radiance: " + err);
+            // SpectrumParameter::Texture radiance (emissive_material.rs:48-79): Albedo-type sRGB texture, looked up at the hit / sampled uv
+            if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, "emissive radiance: " + err);
             break;
         case MI355PT_MAT_GLASS:
         case MI355PT_MAT_PLASTIC:
@@ -346,18 +347,19 @@ int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const
                                         uint32_t illuminant_lut) {
     if (!s || !rgb || !l2w || w == 0 || h == 0) return fail(MI355PT_E_INVALID, "bad environment light arguments");
     SceneImpl& im = s->impl;
-    if (im.env.present) return fail(MI355PT_E_INVALID, "only one environment light per scene is supported on the device");
     if (illuminant_lut >= im.luts.size()) return fail(MI355PT_E_INVALID, "bad illuminant LUT id");
-    im.env.present = true; im.env.intensity = intensity; im.env.w = w; im.env.h = h; im.env.illuminant_lut = illuminant_lut;
-    im.env.rgb.assign(rgb, rgb + (size_t)w * h * 3);
-    std::memcpy(im.env.l2w, l2w, sizeof(float) * 16);
+    SceneImpl::HostEnv he;
+    he.intensity = intensity; he.w = w; he.h = h; he.illuminant_lut = illuminant_lut;
+    he.rgb.assign(rgb, rgb + (size_t)w * h * 3);
+    std::memcpy(he.l2w, l2w, sizeof(float) * 16);
+    im.envs.push_back(std::move(he));
     DevMaterial m{};                         // hidden emissive material: the integrated RgbIlluminantSpectrum, filled in at build()
     m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu; m.intensity = 1.0f; m.color.kind = SPK_CONSTANT;
     im.materials.push_back(m);
     mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE;
     im.mat_descs.push_back(md);
     mi355pt_light_desc ld{}; ld.kind = LK_ENV; ld.intensity = intensity; std::memcpy(ld.local_to_world, l2w, sizeof(float) * 16);
-    im.delta_lights.push_back(HostDeltaLight{ld, (uint32_t)im.materials.size() - 1, (uint32_t)im.instances.size()});
+    im.delta_lights.push_back(HostDeltaLight{ld, (uint32_t)im.materials.size() - 1, (uint32_t)im.instances.size(), (uint32_t)im.envs.size() - 1});
     return MI355PT_OK;
 }
 int mi355pt_scene_add_instance(mi355pt_scene* s, uint32_t geom, uint32_t mat, const float* l2w) {
@@ -569,7 +571,7 @@ int mi355pt_scene_build_multi(mi355pt_scene* s, const mi355pt_camera* cam, int n
             if (!m.scene) { rc = fail(MI355PT_E_INVALID, "allocation failed"); break; }
             SceneImpl& d = m.scene->impl; const SceneImpl& o = s->impl;       // the description, not the lowered state
             d.table = o.table; d.luts = o.luts; d.textures = o.textures; d.meshes = o.meshes; d.mat_descs = o.mat_descs; d.materials = o.materials;
-            d.instances = o.instances; d.env = o.env; d.delta_lights = o.delta_lights; d.bvh_builder = o.bvh_builder;
+            d.instances = o.instances; d.envs = o.envs; d.delta_lights = o.delta_lights; d.bvh_builder = o.bvh_builder;
         }
         rc = mi355pt_scene_build(m.scene, cam);
         if (rc == MI355PT_OK && hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) != hipSuccess) rc = fail(MI355PT_E_DEVICE, "hipStreamCreate failed");

@@ -112,7 +112,7 @@ static_assert(sizeof(DevLightTri) == 64, "light tri");
 
 enum : uint32_t { LK_AREA = 0, LK_POINT = 1, LK_SPOT = 2, LK_DIRECTIONAL = 3, LK_ENV = 4 };
 struct alignas(16) DevLight {
-    uint32_t first_tri, n_tris;   // area: into light_tris
+    uint32_t first_tri, n_tris;   // area: into light_tris; environment light: first_tri = its index in DevScene::envs
     uint32_t material;            // emissive material (delta lights: a hidden one holding the spectrum, intensity 1)
     float area_sum;               // area: sum of triangle areas; delta: the scalar factor of phi (4 pi I, ...), so that
                                   // the light-pick weight is mean_lambda((spectrum * material.intensity) * area_sum) for every kind
@@ -131,7 +131,7 @@ struct DevTexture {
     uint32_t w, h, pad;
 };
 
-// EnvironmentLight (primitive/impls/environment_light.rs): at most one per scene on the device
+// EnvironmentLight (primitive/impls/environment_light.rs): DevScene::envs[DevScene::n_envs], in light-list order
 struct DevEnv {
     const float* texels;          // [h][w][4] float RGB0, row 0 = +y pole
     const float* marginal;        // [h]
@@ -141,7 +141,7 @@ struct DevEnv {
     float l2r[9], r2l[9];         // linear parts, column-major 3x3
     uint32_t illuminant_lut;      // presets::cie_illum_d6500()
     uint32_t light_index;         // position in the light list
-    uint32_t present, pad;
+    uint32_t pad[2];
 };
 
 struct DevScene {
@@ -152,6 +152,7 @@ struct DevScene {
     const DevMaterial* materials;
     const DevLight* lights;
     const DevLightTri* light_tris;
+    const float* light_uvs;       // [n light tris][6]: the emissive triangles' vertex uvs (textured emitters: radiance at the sampled point)
     const float* luts;            // [n_luts][470]
     const float* cmf;             // [470][4]  (xbar, ybar, zbar, 0)
     const float* rgb2spec;        // [3][64][64][64][4]
@@ -162,7 +163,8 @@ struct DevScene {
     uint32_t n_nodes, n_tris, n_lights, n_materials;
     int32_t root;                 // root link (node index, or leaf if the scene has <= MAX_LEAF_TRIS tris)
     uint32_t pad[3];
-    DevEnv env;
+    const DevEnv* envs;           // every infinite light of the scene (Scene sums them all: scene.rs:185-231)
+    uint32_t n_envs, pad_env;
 };
 
 struct DevCamera {

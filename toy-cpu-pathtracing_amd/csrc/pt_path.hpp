@@ -84,23 +84,23 @@ PT_DEV DevSpectrum load_spectrum(const DevSpectrum* p) {
 }
 
 // ---- EnvironmentLight (primitive/impls/environment_light.rs) ----
-PT_DEV void env_spherical(const DevScene& sc, f3 dir_render, float& theta, float& phi) {          // :96-103 after the rotation to local
-    f3 dl = mat3_mul(sc.env.r2l, dir_render);
+PT_DEV void env_spherical(const DevEnv& e, f3 dir_render, float& theta, float& phi) {          // :96-103 after the rotation to local
+    f3 dl = mat3_mul(e.r2l, dir_render);
     theta = fminf(fmaxf(acosf(dl.y), 0.0f), PI_F);
     phi = atan2f(dl.z, dl.x);
     if (phi < 0.0f) phi += 2.0f * PI_F;
 }
 // direction_radiance (:292-305): bilinear texel -> RgbIlluminantSpectrum (scale * sigmoid * D65) -> * intensity
-PT_DEV void env_radiance(const DevScene& sc, f3 dir_render, const Wl& wl, float out[4]) {
+PT_DEV void env_radiance(const DevScene& sc, const DevEnv& e, f3 dir_render, const Wl& wl, float out[4]) {
     float theta, phi;
-    env_spherical(sc, dir_render, theta, phi);
+    env_spherical(e, dir_render, theta, phi);
     float u = fminf(fmaxf(phi / (2.0f * PI_F), 0.0f), 1.0f), v = fminf(fmaxf(theta / PI_F, 0.0f), 1.0f);
-    const uint32_t w = sc.env.w, h = sc.env.h;
+    const uint32_t w = e.w, h = e.h;
     float x = u * (float)(w - 1), y = v * (float)(h - 1);
     uint32_t x0 = (uint32_t)floorf(x), y0 = (uint32_t)floorf(y);
     uint32_t x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
     float fx = x - (float)x0, fy = y - (float)y0;
-    const float4* t = (const float4*)sc.env.texels;
+    const float4* t = (const float4*)e.texels;
     float4 p00 = t[(size_t)y0 * w + x0], p01 = t[(size_t)y0 * w + x1], p10 = t[(size_t)y1 * w + x0], p11 = t[(size_t)y1 * w + x1];
     float rgb[3];
     { float a = p00.x * (1.0f - fx) + p01.x * fx, b = p10.x * (1.0f - fx) + p11.x * fx; rgb[0] = a * (1.0f - fy) + b * fy; }
@@ -110,24 +110,24 @@ PT_DEV void env_radiance(const DevScene& sc, f3 dir_render, const Wl& wl, float 
     if (scale == 0.0f) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }                        // black texel: 0 (the reference divides 0/0)
     float enc[3] = {rgb[0] / scale, rgb[1] / scale, rgb[2] / scale}, c[3];
     rgb2spec_lookup(sc, enc, c);
-    const float* lut = sc.luts + (size_t)sc.env.illuminant_lut * 470;
+    const float* lut = sc.luts + (size_t)e.illuminant_lut * 470;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float val = (scale * sigmoid_value(c[0], c[1], c[2], wl.lam[i])) * lut_value(lut, wl.lam[i]);
-        out[i] = ((i > 0 && wl.term) ? 0.0f : val) * sc.env.intensity;
+        out[i] = ((i > 0 && wl.term) ? 0.0f : val) * e.intensity;
     }
 }
-PT_DEV float env_pdf(const DevScene& sc, f3 dir_render) {                                          // calculate_direction_pdf :212-238
-    if (!(sc.env.total_weight > 0.0f)) return 0.0f;
+PT_DEV float env_pdf(const DevEnv& e, f3 dir_render) {                                          // calculate_direction_pdf :212-238
+    if (!(e.total_weight > 0.0f)) return 0.0f;
     float theta, phi;
-    env_spherical(sc, dir_render, theta, phi);
-    const uint32_t w = sc.env.w, h = sc.env.h;
+    env_spherical(e, dir_render, theta, phi);
+    const uint32_t w = e.w, h = e.h;
     float u = phi / (2.0f * PI_F), v = theta / PI_F;
     uint32_t x = min((uint32_t)floorf(u * (float)w), w - 1), y = min((uint32_t)floorf(v * (float)h), h - 1);
-    float4 p = ((const float4*)sc.env.texels)[(size_t)y * w + x];
+    float4 p = ((const float4*)e.texels)[(size_t)y * w + x];
     float lum = 0.299f * p.x + 0.587f * p.y + 0.114f * p.z;
     float st = fmaxf(sinf(theta), 1e-8f);
-    float pdf_tex = (lum * st) / sc.env.total_weight;
+    float pdf_tex = (lum * st) / e.total_weight;
     float jac = (float)w * (float)h / (2.0f * PI_F * PI_F * st);
     return pdf_tex * jac;
 }
@@ -136,18 +136,28 @@ PT_DEV uint32_t env_sample_cdf(const float* cdf, uint32_t n, float u) {         
     while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (cdf[mid] < u) lo = mid + 1; else hi = mid; }
     return min(lo, n - 1);
 }
-PT_DEV void env_sample(const DevScene& sc, f2 uv, f3& wi, float& pdf_dir) {                        // sample_infinite_light :317-340
-    const uint32_t w = sc.env.w, h = sc.env.h;
-    uint32_t y = env_sample_cdf(sc.env.marginal, h, uv.x);
-    uint32_t x = env_sample_cdf(sc.env.conditional + (size_t)y * w, w, uv.y);
+PT_DEV void env_sample(const DevEnv& e, f2 uv, f3& wi, float& pdf_dir) {                        // sample_infinite_light :317-340
+    const uint32_t w = e.w, h = e.h;
+    uint32_t y = env_sample_cdf(e.marginal, h, uv.x);
+    uint32_t x = env_sample_cdf(e.conditional + (size_t)y * w, w, uv.y);
     float u = ((float)x + 0.5f) / (float)w, v = ((float)y + 0.5f) / (float)h;
     float theta = v * PI_F, phi = u * 2.0f * PI_F;
     float s_t, c_t, s_p, c_p; sincosf(theta, &s_t, &c_t); sincosf(phi, &s_p, &c_p);
     f3 wl = mk3(s_t * c_p, c_t, s_t * s_p);
-    wi = mat3_mul(sc.env.l2r, wl);
-    pdf_dir = env_pdf(sc, wi);
+    wi = mat3_mul(e.l2r, wl);
+    pdf_dir = env_pdf(e, wi);
 }
 
+// Scene::evaluate_infinite_light_radiance (scene.rs:208-231): every infinite light's radiance along the direction, summed
+PT_DEV void env_radiance_all(const DevScene& sc, f3 dir_render, const Wl& wl, float out[4]) {
+    env_radiance(sc, sc.envs[0], dir_render, wl, out);
+    for (uint32_t k = 1; k < sc.n_envs; ++k) {
+        float r[4];
+        env_radiance(sc, sc.envs[k], dir_render, wl, r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = out[i] + r[i];
+    }
+}
 PT_DEV float balance_heuristic(float a, float b) { return (a == 0.0f && b == 0.0f) ? 0.0f : a / (a + b); }   // common.rs:15-20
 
 // fresnel_dielectric for one wavelength lane (material/common.rs:87-105); spectrum '/' maps x/0 -> 0
@@ -246,9 +256,9 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
 
     if (!got) {
         end_path = true;
-        if ((FEAT & FEAT_ENV) && sc.env.present) {
+        if ((FEAT & FEAT_ENV) && sc.n_envs != 0u) {
             float rad[4];
-            env_radiance(sc, rd, wl, rad);
+            env_radiance_all(sc, rd, wl, rad);
             if (from_camera) {                                               // base_renderer.rs:180-187
 #pragma unroll
                 for (int i = 0; i < 4; ++i) L[i] = L[i] + T[i] * rad[i];
@@ -256,9 +266,38 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) L[i] = L[i] + sdiv((T[i] * pf[i]) * rad[i], p_pdf);
             } else if (prm.strategy == 2u) {                                 // mis_renderer.rs:183-230 (also for specular samples)
-                // pdf_infinite_light_sample: probability among the INFINITE lights (1 with one environment light whose
-                // weight is non-zero, light_sampler.rs:115-153) times the direction pdf
-                float light_pdf = 1.0f * env_pdf(sc, rd);
+                // Scene::pdf_infinite_light_sample (scene.rs:185-206): sum over the infinite lights of (probability among the INFINITE
+                // lights, light_sampler.rs:115-153) x (direction pdf).  One environment light with a non-zero weight: probability 1.
+                float light_pdf = 0.0f;
+                if (sc.n_envs == 1u) light_pdf = 1.0f * env_pdf(sc.envs[0], rd);
+                else {
+                    float inf_sum = 0.0f;
+                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                        DevLight lt = sc.lights[li];
+                        if (lt.kind != LK_ENV) continue;
+                        const DevMaterial* lm = sc.materials + lt.material;
+                        float ph[4];
+                        DevSpectrum ls = load_spectrum(&lm->color);
+                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                        inf_sum += sum / 4.0f;
+                    }
+                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                        DevLight lt = sc.lights[li];
+                        if (lt.kind != LK_ENV) continue;
+                        const DevMaterial* lm = sc.materials + lt.material;
+                        float ph[4];
+                        DevSpectrum ls = load_spectrum(&lm->color);
+                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                        const float probability = inf_sum == 0.0f ? 0.0f : (sum / 4.0f) / inf_sum;
+                        light_pdf += probability * env_pdf(sc.envs[lt.first_tri], rd);
+                    }
+                }
                 float w = balance_heuristic(p_pdf, light_pdf);
                 float tf = 1.0f / p_pdf;
 #pragma unroll
@@ -293,12 +332,20 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                     // Scene::pdf_light_sample (scene.rs:156-182); light probability = phi-weighted pick
                     float wsum = 0.0f, wme = 0.0f;
                     if (!(FEAT & FEAT_MLIGHT) || sc.n_lights == 1u) {
-                        // one light (every BASELINE config): phi(lambda) is Le * area, already evaluated
-                        // (emissive radiance cannot be a texture, so Le does not depend on uv)
+                        // one light (every BASELINE config): phi(lambda) is Le * area, already evaluated — unless the radiance is a
+                        // texture, whose phi is taken at uv (0.5, 0.5) (EmissiveMaterial::average_intensity, emissive_material.rs:61-79)
                         float sum = 0.0f;
                         float area = sc.lights[0].area_sum;
+                        if ((FEAT & FEAT_TEX) && mat->color.kind == SPK_TEXTURE) {
+                            float ph[4];
+                            DevSpectrum ls = load_spectrum(&mat->color);
+                            eval_spectrum<false, true>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += Le[i] * area;
+                            for (int i = 0; i < 4; ++i) sum += (ph[i] * mat->intensity) * area;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sum += Le[i] * area;
+                        }
                         wsum = wme = sum / 4.0f;
                     } else
                     for (uint32_t li = 0; li < sc.n_lights; ++li) {
@@ -306,7 +353,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float inten = lm->intensity;
                         float sum = 0.0f;
 #pragma unroll
@@ -737,7 +784,8 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                 if (!(FEAT & FEAT_MLIGHT) || sc.n_lights == 1u) {
                     const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
                     DevSpectrum ls0 = load_spectrum(&lm0->color);
-                    eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ls0, wl, f2{0.0f, 0.0f}, lrad, st);
+                    // (a textured radiance: phi at uv (0.5, 0.5), emissive_material.rs:61-79; the radiance itself follows at the sampled point)
+                    eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ls0, wl, f2{0.5f, 0.5f}, lrad, st);
                     float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
@@ -748,7 +796,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
@@ -761,7 +809,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, false>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
@@ -785,9 +833,10 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     float dl_scale = 1.0f;                                      // delta lights: falloff
                     float env_rad[4] = {0, 0, 0, 0};
                     if ((FEAT & FEAT_ENV) && lt.kind == LK_ENV) {               // sample_infinite_light (environment_light.rs:317-340)
-                        env_sample(sc, luv, wi_r, pdf_dir);
+                        const DevEnv& e = sc.envs[lt.first_tri];
+                        env_sample(e, luv, wi_r, pdf_dir);
                         dv = wi_r;
-                        env_radiance(sc, wi_r, wl, env_rad);
+                        env_radiance(sc, e, wi_r, wl, env_rad);
                     } else if ((FEAT & FEAT_DELTA) && lt.kind != LK_AREA) {
                         // Scene::calculate_light for PrimitiveDelta{Point,Directional}Light (scene.rs:114-139)
                         if (lt.kind == LK_DIRECTIONAL) {                        // directional_light.rs:95-107
@@ -816,6 +865,12 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
                     float b2 = 1.0f - b0 - b1;
                     f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
+                    if ((FEAT & FEAT_TEX) && lm->color.kind == SPK_TEXTURE) {      // EmissiveMaterial::radiance at the sampled point's uv (:48-59, emissive_triangle_mesh.rs:237-247)
+                        const float* tu = sc.light_uvs + (size_t)(lt.first_tri + tsel) * 6;
+                        const f2 suv = f2{tu[0] * b0 + tu[2] * b1 + tu[4] * b2, tu[1] * b0 + tu[3] * b1 + tu[5] * b2};
+                        DevSpectrum lsx = load_spectrum(&lm->color);
+                        eval_spectrum<STATS, true>(sc, lsx, wl, suv, lrad, st);
+                    }
                     ln = mk3(qc.z, qc.w, qd.x);                                  // normalize(normalize(cross(p1 - p0, p2 - p0))), precomputed
                     pdf_a = 1.0f / lt.area_sum;
                     dv = lp - sf.p;

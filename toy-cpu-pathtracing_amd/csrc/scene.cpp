@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -192,11 +193,12 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     std::vector<BuildTri> btris;
     std::vector<DevLight> lights;
     std::vector<DevLightTri> light_tris;
+    std::vector<float> light_uvs;            // 6 per light triangle (original vertex order), zeros without texcoords
 
     // delta lights enter the light list in creation order, interleaved with the emissive instances
     size_t next_delta = 0;
-    uint32_t env_light_index = 0;
-    float env_l2r[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::vector<uint32_t> env_light_index(envs.size(), 0u);                  // position of environment light k in the light list
+    std::vector<std::array<float, 16>> env_l2r(envs.size());
     float sb_lo[3] = {INFINITY, INFINITY, INFINITY}, sb_hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // scene bounds (render space)
     auto push_delta = [&](const HostDeltaLight& hl) {
         DevLight dl{};
@@ -206,8 +208,9 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         mat4_mul(w2r, hl.d.local_to_world, l2r);
         if (hl.d.kind == LK_ENV) {                                              // EnvironmentLight: phi = intensity * integrated spectrum
             dl.area_sum = hl.d.intensity;
-            env_light_index = (uint32_t)lights.size();
-            std::memcpy(env_l2r, l2r, sizeof(env_l2r));
+            dl.first_tri = hl.env_index;                                        // DevScene::envs index
+            env_light_index[hl.env_index] = (uint32_t)lights.size();
+            std::memcpy(env_l2r[hl.env_index].data(), l2r, sizeof(float) * 16);
             lights.push_back(dl);
             return;
         }
@@ -318,6 +321,10 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
                 lt.cdf = area_table[t];
                 { V3 g = normalize(normalize(cross(q[1] - q[0], q[2] - q[0]))); lt.n[0] = g.x; lt.n[1] = g.y; lt.n[2] = g.z; }
                 light_tris.push_back(lt);
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t v = mesh.idx[3 * t + k];
+                    light_uvs.push_back(mesh.uv.empty() ? 0.0f : mesh.uv[2 * v]); light_uvs.push_back(mesh.uv.empty() ? 0.0f : mesh.uv[2 * v + 1]);
+                }
             }
             shade_unordered.push_back(sh);
         }
@@ -380,9 +387,13 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     }
 
     // EnvironmentLight::new (environment_light.rs:28-75) + build_2d_cdf (:153-199)
-    std::vector<float> env_texels, env_marginal, env_conditional;
-    DevEnv denv{};
-    if (env.present) {
+    std::vector<std::vector<float>> all_texels(envs.size()), all_marginal(envs.size()), all_conditional(envs.size());
+    std::vector<DevEnv> denvs(envs.size());
+    for (size_t ek = 0; ek < envs.size(); ++ek) {
+        const HostEnv& env = envs[ek];
+        std::vector<float>&env_texels = all_texels[ek], &env_marginal = all_marginal[ek], &env_conditional = all_conditional[ek];
+        DevEnv& denv = denvs[ek];
+        const float* env_l2r_k = env_l2r[ek].data();
         if (table.empty()) { *err = "environment light needs the rgb2spec table"; return MI355PT_E_INVALID; }
         const uint32_t w = env.w, h = env.h;
         float tot[3] = {0, 0, 0};
@@ -394,7 +405,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         }
         float n = (float)(w * h);
         for (int c = 0; c < 3; ++c) tot[c] /= n;
-        DevMaterial& hm = materials[lights[env_light_index].material];     // integrated RgbIlluminantSpectrum (rgb_illuminant_spectrum.rs:26-41)
+        DevMaterial& hm = materials[lights[env_light_index[ek]].material];     // integrated RgbIlluminantSpectrum (rgb_illuminant_spectrum.rs:26-41)
         float scale = 2.0f * std::fmax(tot[0], std::fmax(tot[1], tot[2]));
         if (scale == 0.0f) { hm.color.kind = SPK_CONSTANT; hm.color.c[0] = 0.0f; }
         else {
@@ -424,8 +435,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         float cum = 0.0f;
         for (uint32_t y = 0; y < h; ++y) { cum += row_w[y]; env_marginal[y] = total > 0.0f ? cum / total : (float)(y + 1) / (float)h; }
         denv.w = w; denv.h = h; denv.total_weight = total; denv.intensity = env.intensity; denv.illuminant_lut = env.illuminant_lut;
-        denv.light_index = env_light_index; denv.present = 1;
-        double a[9] = {env_l2r[0], env_l2r[1], env_l2r[2], env_l2r[4], env_l2r[5], env_l2r[6], env_l2r[8], env_l2r[9], env_l2r[10]};
+        denv.light_index = env_light_index[ek];
+        double a[9] = {env_l2r_k[0], env_l2r_k[1], env_l2r_k[2], env_l2r_k[4], env_l2r_k[5], env_l2r_k[6], env_l2r_k[8], env_l2r_k[9], env_l2r_k[10]};
         for (int i = 0; i < 9; ++i) denv.l2r[i] = (float)a[i];
         double det = a[0] * (a[4] * a[8] - a[7] * a[5]) - a[3] * (a[1] * a[8] - a[7] * a[2]) + a[6] * (a[1] * a[5] - a[4] * a[2]);
         double inv[9] = {(a[4] * a[8] - a[7] * a[5]) / det, -(a[1] * a[8] - a[7] * a[2]) / det, (a[1] * a[5] - a[4] * a[2]) / det,
@@ -457,24 +468,26 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     }
     if ((rc = upload(this, lights, &dev.lights, err))) return rc;
     if ((rc = upload(this, light_tris, &dev.light_tris, err))) return rc;
+    if ((rc = upload(this, light_uvs, &dev.light_uvs, err))) return rc;
     if ((rc = upload(this, lut_pool, &dev.luts, err))) return rc;
     if ((rc = upload(this, cmf, &dev.cmf, err))) return rc;
     if ((rc = upload(this, tab4, &dev.rgb2spec, err))) return rc;
     if ((rc = upload(this, znodes, &dev.z_nodes, err))) return rc;
     if ((rc = upload(this, texels, &dev.texels, err))) return rc;
     if ((rc = upload(this, dtex, &dev.textures, err))) return rc;
-    if (env.present) {
-        if ((rc = upload(this, env_texels, &denv.texels, err))) return rc;
-        if ((rc = upload(this, env_marginal, &denv.marginal, err))) return rc;
-        if ((rc = upload(this, env_conditional, &denv.conditional, err))) return rc;
+    for (size_t ek = 0; ek < envs.size(); ++ek) {
+        if ((rc = upload(this, all_texels[ek], &denvs[ek].texels, err))) return rc;
+        if ((rc = upload(this, all_marginal[ek], &denvs[ek].marginal, err))) return rc;
+        if ((rc = upload(this, all_conditional[ek], &denvs[ek].conditional, err))) return rc;
     }
-    dev.env = denv;
+    if ((rc = upload(this, denvs, &dev.envs, err))) return rc;
+    dev.n_envs = (uint32_t)envs.size();
     dev.n_nodes = (uint32_t)bvh.nodes.size(); dev.n_tris = (uint32_t)tris.size();
     dev.n_lights = (uint32_t)lights.size(); dev.n_materials = (uint32_t)materials.size();
     dev.root = bvh.root;
     features = lights.size() == 1 ? 0u : FEAT_MLIGHT;
     if (!delta_lights.empty()) features |= FEAT_DELTA;
-    if (env.present) features |= FEAT_ENV;
+    if (!envs.empty()) features |= FEAT_ENV;
     for (const HostInstance& inst : instances) {
         const DevMaterial& m = materials[inst.mat];
         if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | ((m.roughness >= 1e-3f || m.roughness_tex != 0xffffffffu) ? FEAT_ROUGH : 0u);

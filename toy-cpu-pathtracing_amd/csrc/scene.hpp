@@ -16,7 +16,7 @@ struct HostMesh {
     uint32_t n_vert = 0, n_tri = 0;
 };
 struct HostInstance { uint32_t geom, mat; float l2w[16]; };
-struct HostDeltaLight { mi355pt_light_desc d; uint32_t material; uint32_t after_instances; };   // hidden emissive material holds the spectrum
+struct HostDeltaLight { mi355pt_light_desc d; uint32_t material; uint32_t after_instances; uint32_t env_index = 0; };   // hidden emissive material holds the spectrum
 
 struct BuildTri { float lo[3], hi[3], c[3]; };
 struct BvhOut {
@@ -50,7 +50,8 @@ struct SceneImpl {
     std::vector<mi355pt_material_desc> mat_descs;
     std::vector<DevMaterial> materials;
     std::vector<HostInstance> instances;
-    struct HostEnv { float intensity = 1.0f; uint32_t w = 0, h = 0, illuminant_lut = 0; std::vector<float> rgb; float l2w[16]; bool present = false; } env;
+    struct HostEnv { float intensity = 1.0f; uint32_t w = 0, h = 0, illuminant_lut = 0; std::vector<float> rgb; float l2w[16]; };
+    std::vector<HostEnv> envs;                  // environment lights in creation order (HostDeltaLight::d.angle_inner carries the index)
     std::vector<HostDeltaLight> delta_lights;   // creation order; after_instances = instances.size() at creation (light_sampler.rs:163-180)
     // ---- lowered ----
     bool built = false;

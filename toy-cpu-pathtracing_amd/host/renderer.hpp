@@ -290,6 +290,111 @@ inline std::vector<float> load_pfm(const std::string& path, uint32_t* w, uint32_
     for (uint32_t y = 0; y < *h; ++y) std::memcpy(&out[(size_t)y * *w * 3], &raw[(size_t)(*h - 1 - y) * *w * 3], (size_t)*w * 3 * sizeof(float));
     return out;
 }
+// float RGB environment maps as the reference reads them: OpenEXR through image::open(..).to_rgb32f() (environment_light.rs:30-41).
+// Own reader for the scanline subset HDR skies ship in: single part, NO / ZIPS / ZIP compression (the zlib inflate above + OpenEXR's
+// byte predictor and de-interleave), HALF or FLOAT channels R, G, B (other channels such as A are skipped), either line order.
+// Returns top-to-bottom h*w*3.  PIZ / PXR24 / B44 / DWA, tiles, deep and multi-part files are refused with a message.
+namespace exr_detail {
+inline float half_to_float(uint16_t h) {
+    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = s;
+        else { int sh = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; ++sh; } u = s | ((uint32_t)(113 - sh) << 23) | ((mm & 1023u) << 13); }   // subnormal
+    } else if (e == 31) u = s | 0x7f800000u | (m << 13);
+    else u = s | ((e + 112u) << 23) | (m << 13);
+    float f; std::memcpy(&f, &u, 4); return f;
+}
+}
+inline std::vector<float> load_exr(const std::string& path, uint32_t* w_out, uint32_t* h_out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open environment map " + path);
+    std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    size_t p = 0;
+    auto need = [&](size_t n) { if (p + n > d.size()) throw std::runtime_error(path + ": truncated EXR"); };
+    auto rd32 = [&]() { need(4); uint32_t v; std::memcpy(&v, &d[p], 4); p += 4; return v; };
+    auto rdstr = [&]() { std::string s; for (;;) { need(1); char c = (char)d[p++]; if (!c) break; s.push_back(c); if (s.size() > 255) throw std::runtime_error(path + ": bad EXR string"); } return s; };
+    if (rd32() != 20000630u) throw std::runtime_error(path + ": not an OpenEXR file");
+    const uint32_t version = rd32();
+    if ((version & 0xffu) != 2u || (version & 0x1a00u)) throw std::runtime_error(path + ": tiled / deep / multi-part EXR files are not supported (scanline only)");
+    struct Chan { std::string name; uint32_t type; };
+    std::vector<Chan> chans;
+    int compression = -1, line_order = 0; int32_t win[4] = {0, 0, -1, -1}; bool have_win = false;
+    for (;;) {
+        std::string name = rdstr();
+        if (name.empty()) break;
+        std::string type = rdstr();
+        const uint32_t size = rd32();
+        need(size);
+        const size_t q = p;
+        if (name == "channels") {
+            size_t c = q;
+            while (c < q + size && d[c]) {
+                Chan ch; while (d[c]) ch.name.push_back((char)d[c++]); ++c;
+                std::memcpy(&ch.type, &d[c], 4); c += 4 + 4;       // pixel type; pLinear + 3 reserved
+                uint32_t xs, ys; std::memcpy(&xs, &d[c], 4); std::memcpy(&ys, &d[c + 4], 4); c += 8;
+                if (xs != 1 || ys != 1) throw std::runtime_error(path + ": sub-sampled EXR channels are not supported");
+                chans.push_back(ch);
+            }
+        } else if (name == "compression") compression = d[q];
+        else if (name == "dataWindow") { std::memcpy(win, &d[q], 16); have_win = true; }
+        else if (name == "lineOrder") line_order = d[q];
+        p = q + size;
+    }
+    if (!have_win || chans.empty() || compression < 0) throw std::runtime_error(path + ": EXR header lacks channels / compression / dataWindow");
+    if (compression != 0 && compression != 2 && compression != 3) throw std::runtime_error(path + ": EXR compression " + std::to_string(compression) + " is not supported (NONE, ZIPS, ZIP are)");
+    const uint32_t w = (uint32_t)(win[2] - win[0] + 1), h = (uint32_t)(win[3] - win[1] + 1);
+    int idx[3] = {-1, -1, -1};
+    size_t line_bytes = 0; std::vector<size_t> chan_off(chans.size());
+    for (size_t i = 0; i < chans.size(); ++i) {
+        if (chans[i].type != 1 && chans[i].type != 2) throw std::runtime_error(path + ": EXR UINT channels are not supported");
+        chan_off[i] = line_bytes; line_bytes += (size_t)w * (chans[i].type == 1 ? 2 : 4);
+        if (chans[i].name == "R") idx[0] = (int)i;
+        if (chans[i].name == "G") idx[1] = (int)i;
+        if (chans[i].name == "B") idx[2] = (int)i;
+    }
+    if (idx[0] < 0 && chans.size() == 1) idx[0] = idx[1] = idx[2] = 0;      // a luminance-only file: grey (to_rgb32f does the same)
+    if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) throw std::runtime_error(path + ": EXR file has no R, G, B channels");
+    const uint32_t lines_per_block = compression == 3 ? 16u : 1u, n_blocks = (h + lines_per_block - 1) / lines_per_block;
+    need((size_t)n_blocks * 8); p += (size_t)n_blocks * 8;                    // the offset table: chunks are read in file order instead
+    std::vector<float> out((size_t)w * h * 3);
+    (void)line_order;                                                          // every chunk carries its own y
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const int32_t y0 = (int32_t)rd32(); const uint32_t size = rd32();
+        need(size);
+        if (y0 < win[1] || y0 > win[3]) throw std::runtime_error(path + ": EXR chunk outside the data window");
+        const uint32_t rows = std::min<uint32_t>(lines_per_block, (uint32_t)(win[3] - y0 + 1));
+        const size_t raw_size = line_bytes * rows;
+        std::vector<uint8_t> raw;
+        if (compression == 0 || size == raw_size) raw.assign(d.begin() + (long)p, d.begin() + (long)(p + size));
+        else {
+            std::vector<uint8_t> t = png_detail::inflate(&d[p], size);
+            if (t.size() != raw_size) throw std::runtime_error(path + ": EXR chunk inflates to the wrong size");
+            for (size_t i = 1; i < t.size(); ++i) t[i] = (uint8_t)(t[i - 1] + t[i] - 128);          // predictor
+            raw.resize(raw_size);
+            const size_t half = (raw_size + 1) / 2;
+            for (size_t i = 0; i < raw_size; ++i) raw[i] = (i & 1) ? t[half + i / 2] : t[i / 2];       // de-interleave the two halves
+        }
+        if (raw.size() != raw_size) throw std::runtime_error(path + ": EXR chunk has the wrong size");
+        p += size;
+        for (uint32_t r = 0; r < rows; ++r) {
+            const uint8_t* line = &raw[line_bytes * r];
+            float* o = &out[(size_t)(y0 - win[1] + (int32_t)r) * w * 3];
+            for (int c = 0; c < 3; ++c) {
+                const Chan& ch = chans[(size_t)idx[c]]; const uint8_t* src = line + chan_off[(size_t)idx[c]];
+                for (uint32_t x = 0; x < w; ++x) {
+                    if (ch.type == 1) { uint16_t hv; std::memcpy(&hv, src + 2 * x, 2); o[3 * x + c] = exr_detail::half_to_float(hv); }
+                    else std::memcpy(&o[3 * x + c], src + 4 * x, 4);
+                }
+            }
+        }
+    }
+    *w_out = w; *h_out = h;
+    return out;
+}
+inline std::vector<float> load_float_image(const std::string& path, uint32_t* w, uint32_t* h) {   // by extension: .exr like the reference's sky, .pfm for the stand-in
+    return path.size() >= 4 && path.compare(path.size() - 4, 4, ".exr") == 0 ? load_exr(path, w, h) : load_pfm(path, w, h);
+}
 inline ImageRgb8 load_image(const std::string& path) {      // by extension: .png like the reference's assets, .ppm for the synthetic stand-ins
     return path.size() >= 4 && path.compare(path.size() - 4, 4, ".png") == 0 ? load_png(path) : load_ppm(path);
 }
@@ -499,7 +604,7 @@ struct GeometryPrimitive { GeometryIndex geometry_index; Material surface_materi
 // CreatePrimitiveDesc::{SingleTriangle,PointLight,SpotLight,DirectionalLight}Primitive (primitive/create_desc.rs:17-66)
 struct SingleTrianglePrimitive { Vec3 positions[3]; Vec3 normals[3]; float uvs[3][2]; Material surface_material; Transform transform; };
 struct PointLightPrimitive { float intensity; Spectrum spectrum; Transform transform; };
-struct EnvironmentLightPrimitive { float intensity; std::string texture_path; Transform transform; };   // .pfm here (the reference: .exr)
+struct EnvironmentLightPrimitive { float intensity; std::string texture_path; Transform transform; };   // .exr like the reference, or .pfm
 struct SpotLightPrimitive { float angle_inner, angle_outer, intensity; Spectrum spectrum; Transform transform; };
 struct DirectionalLightPrimitive { float intensity; Spectrum spectrum; Transform transform; };
 
@@ -557,7 +662,7 @@ public:
     }
     void create_primitive(const EnvironmentLightPrimitive& d) {
         uint32_t w = 0, h = 0;
-        std::vector<float> rgb = load_pfm(d.texture_path, &w, &h);
+        std::vector<float> rgb = load_float_image(d.texture_path, &w, &h);                 // EXR (environment_light.rs:30-41) or PFM
         mi355pt_spectrum d65 = lower_spectrum(presets::cie_illum_d6500());       // rgb_illuminant_spectrum.rs:28
         check(mi355pt_scene_add_environment_light(s_, d.intensity, rgb.data(), w, h, d.transform.m, d65.id), "mi355pt_scene_add_environment_light");
     }

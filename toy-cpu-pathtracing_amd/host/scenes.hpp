@@ -159,7 +159,7 @@ inline void load_scene_16_18(Scene& scene, Camera& camera, bool thickness_map) {
     camera.set_look_to({0.0f, 3.15221f, 6.0f}, {0.0f, -0.9f, -3.2f}, {0.0f, 1.0f, 0.0f});
 }
 inline void load_scene_19(Scene& scene, Camera& camera) {           // scene_19.rs:17-153: three heroes under an environment light
-    // stand-ins: constant metallic / roughness instead of the FloatTexture maps, PFM sky
+    // stand-ins: constant metallic / roughness instead of the FloatTexture maps, synthetic sky (PFM unless the real EXR is present)
     GeometryIndex floor_geom = scene.load_obj(asset("yuka.obj"));
     scene.create_primitive(GeometryPrimitive{floor_geom, LambertMaterial::create(SpectrumParameter::constant(RgbAlbedoSpectrum::create(ColorSrgb{0.8f, 0.8f, 0.8f})), NormalParameter::none()),
                                              Transform::identity()});
@@ -178,7 +178,11 @@ inline void load_scene_19(Scene& scene, Camera& camera) {           // scene_19.
                                              PlasticMaterial::create(1.5f, SpectrumParameter::constant(RgbAlbedoSpectrum::create(ColorSrgbLinear{0.4f, 0.9f, 1.0f})), NormalParameter::none(), false,
                                                                      FloatParameter::constant(0.0f)),
                                              Transform::identity().translate({-0.5f, 0.0f, -0.5f})});
-    scene.create_primitive(EnvironmentLightPrimitive{1.0f, asset("sky/scythian_tombs_2_1k.pfm"), Transform::identity()});
+    {   // scene_19.rs reads sky/scythian_tombs_2_1k.exr (an LFS object); the synthetic stand-in is exported as .pfm
+        std::string sky = asset("sky/scythian_tombs_2_1k.exr");
+        if (!std::ifstream(sky)) sky = asset("sky/scythian_tombs_2_1k.pfm");
+        scene.create_primitive(EnvironmentLightPrimitive{1.0f, sky, Transform::identity()});
+    }
     camera.set_look_to({-1.5f, 0.8f, 2.5f}, {1.5f, -0.4f, -2.5f}, {0.0f, 1.0f, 0.0f});
 }
 inline void load_scene_6(Scene& scene, Camera& camera) {            // scene_6.rs:13-110: smooth gold hero

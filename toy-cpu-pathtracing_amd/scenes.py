@@ -330,6 +330,31 @@ def load_scene(scene, scene_id, width, height, tex_size=1024, build=True):
         scene.add_instance(g, scene.add_material(d), _mat4_trs_scene17())
         _room(scene, p)
         cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 29:   # not a reference scene: TWO environment lights (Scene sums every infinite light, scene.rs:185-231; the MIS weight
+        # sums probability x direction pdf over them, mis_renderer.rs:205-214) over a floor, a Lambert and a smooth-gold hero
+        room = _asset("room")
+        scene.add_instance(scene.add_mesh(room["yuka"]), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        g = scene.add_mesh(_asset("bunny"))
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.6, 0.3))), _translate(-0.6, 0.0, 0.0))
+        d = MaterialDesc(); d.type = MAT_METAL; d.eta = Spectrum.lut(scene.add_lut470(p["au_eta"])); d.k = Spectrum.lut(scene.add_lut470(p["au_k"]))
+        d.normal_tex = NONE; d.roughness = 0.0; d.color = Spectrum.constant(1.0)
+        scene.add_instance(g, scene.add_material(d), _translate(0.6, 0.0, 0.0))
+        d65 = scene.add_lut470(p["cie_illum_d6500"])
+        scene.add_environment_light(1.0, assets.sky_envmap(), d65)
+        scene.add_environment_light(0.35, assets.sky_envmap(64, 32, seed=11), d65, _rot_y(140.0))
+        cam = make_camera((-1.5, 0.8, 2.5), (1.5, -0.4, -2.5), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 30:   # not a reference scene: a TEXTURED emitter (SpectrumParameter::Texture radiance, emissive_material.rs:48-79: looked up at
+        # the hit / sampled uv, its light-pick weight at uv (0.5, 0.5)) — a uv-mapped panel under the ceiling of the Cornell room
+        g = scene.add_mesh(_asset("bunny"))
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        _room(scene, p, with_light=False)
+        albedo, _ = _asset(f"tex{min(tex_size, 256)}")
+        panel = assets.load_obj_semantics(dict(pos=np.array([[-0.9, 3.95, -0.9], [0.9, 3.95, -0.9], [0.9, 3.95, 0.9], [-0.9, 3.95, 0.9]], np.float32),
+                                               nrm=np.array([[0, -1, 0]] * 4, np.float32), uv=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32),
+                                               idx=np.array([[0, 1, 2], [0, 2, 3]], np.uint32)))
+        em = MaterialDesc(); em.type = MAT_EMISSIVE; em.color = Spectrum.texture_albedo_srgb(scene.add_tex_rgb8(albedo)); em.intensity = 12.0; em.normal_tex = NONE
+        scene.add_instance(scene.add_mesh(panel), scene.add_material(em))
+        cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
     else:
         raise ValueError(f"scene {scene_id} is outside the hot-path scope (SURVEY.md §8)")
     if build:
