@@ -231,6 +231,12 @@ int mi355pt_quantize_u8(const float* rgb, size_t n, uint8_t* out);
  * entry.  The parity tests hand the tree to the oracle, which walks it to check the instrumented kernel's step counts. */
 int mi355pt_scene_export_bvh(const mi355pt_scene* s, void* out_nodes, uint32_t* n_nodes, void* out_tris, uint32_t* n_tris,
                              int32_t* root);
+/* Host-only check of the acceleration structure the render path walks (no reference counterpart): builds the sweep-SAH BVH2 over the
+ * n_tris triangles (9 floats each), collapses it to the 4-wide tree of the cooperative traversals and walks BOTH on the CPU for n_rays rays
+ * (6 floats each: origin, direction): out_mismatch = rays for which the two trees reach different sets of leaves (must be 0);
+ * out_info[4] = {BVH2 nodes, BVH4 nodes, BVH2 depth, worst-case stack entries of the BVH4 (< 24 by construction)}. */
+int mi355pt_probe_bvh_collapse(const float* tri_pos, uint32_t n_tris, const float* rays_od, uint32_t n_rays, uint32_t* out_info,
+                               uint32_t* out_mismatch);
 /* ZSobolSampler: for each query (x, y, sample_index) emit n_dims raw 32-bit Sobol outputs following the draw
  * pattern string `pattern` of '1' (get_1d) and '2' (get_2d) characters.  z_sobol_sampler.rs:198-230 */
 int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t seed, const uint32_t* xys /* n*3 */,

@@ -23,6 +23,7 @@ ap.add_argument("--sampler", default="sobol")
 ap.add_argument("--tag", default="")
 ap.add_argument("--max-depth", type=int, default=16)
 ap.add_argument("--shards", type=int, default=1, help="render only shard 0 of N (emulates one rank of an N-GPU job)")
+ap.add_argument("--tex-size", type=int, default=1024)
 ap.add_argument("--no-stats", action="store_true", help="skip the instrumented launch (PC sampling wants only the production kernel)")
 a = ap.parse_args()
 
@@ -30,7 +31,7 @@ pkg = importlib.import_module("toy-cpu-pathtracing_amd")
 import ctypes as C
 prod = pkg.Product()
 sc = prod.new_scene()
-cam = pkg.scenes.load_scene(sc, a.scene, a.width, a.height)
+cam = pkg.scenes.load_scene(sc, a.scene, a.width, a.height, tex_size=a.tex_size)
 hip = C.CDLL("libamdhip64.so")
 n = a.width * a.height * 3 * 4
 d_acc = C.c_void_p()

@@ -131,8 +131,8 @@ struct DevBuf {
 };
 
 int resident_waves(uint32_t feat) {
-    static int cached[256] = {0};
-    int& c = cached[feat & 255u];
+    static int cached[512] = {0};
+    int& c = cached[feat & 511u];
     if (!c) c = query_resident_waves(feat);
     return c;
 }
@@ -689,6 +689,53 @@ int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t 
     HIP_TRY(hipMemcpy(d_pat.p, pattern, n_pat, hipMemcpyHostToDevice));
     HIP_TRY(launch_probe_sobol(width, seed, log2_spp, nb4, d_xys.p, n, d_pat.p, n_pat, per, d_out.p, nullptr));
     HIP_TRY(hipMemcpy(out_bits, d_out.p, sizeof(uint32_t) * (size_t)n * per, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+
+// Host-only: sweep-SAH BVH2 over n triangles + the BVH4 collapse, both walked on the CPU for n_rays rays (closest hit over the triangle
+// boxes' entry distances is not the point — the point is that both trees return the SAME set of leaves for every ray, i.e. the collapse
+// loses nothing, and that the collapsed tree's worst-case stack need stays inside STACK_DEPTH).  No device involved.
+int mi355pt_probe_bvh_collapse(const float* tri_pos, uint32_t n_tris, const float* rays_od, uint32_t n_rays, uint32_t* out_info, uint32_t* out_mismatch) {
+    if (!tri_pos || !out_info || n_tris == 0) return fail(MI355PT_E_INVALID, "bad argument");
+    std::vector<BuildTri> bt(n_tris);
+    for (uint32_t i = 0; i < n_tris; ++i) for (int a = 0; a < 3; ++a) {
+        const float v0 = tri_pos[9 * i + a], v1 = tri_pos[9 * i + 3 + a], v2 = tri_pos[9 * i + 6 + a];
+        bt[i].lo[a] = std::fmin(v0, std::fmin(v1, v2)); bt[i].hi[a] = std::fmax(v0, std::fmax(v1, v2)); bt[i].c[a] = 0.5f * (bt[i].lo[a] + bt[i].hi[a]);
+    }
+    BvhOut bvh; build_bvh(bt, &bvh);
+    std::vector<DevNode4> n4; int32_t root4 = 0; int max_stack = 0; std::string err;
+    if (!collapse_bvh4(bvh.nodes, bvh.root, bvh.order.size(), &n4, &root4, &max_stack, &err)) return fail(MI355PT_E_INVALID, err);
+    out_info[0] = (uint32_t)bvh.nodes.size(); out_info[1] = (uint32_t)n4.size(); out_info[2] = (uint32_t)bvh.max_depth; out_info[3] = (uint32_t)max_stack;
+    uint32_t mism = 0;
+    auto slab = [](const float lo[3], const float hi[3], const float* o, const float* inv) {
+        float tn = 0.0f, tf = 3.0e38f;
+        for (int a = 0; a < 3; ++a) { float l = (lo[a] - o[a]) * inv[a], h = (hi[a] - o[a]) * inv[a]; tn = std::fmax(tn, std::fmin(l, h)); tf = std::fmin(tf, std::fmax(l, h)); }
+        return tn <= tf;
+    };
+    for (uint32_t r = 0; rays_od && r < n_rays; ++r) {
+        const float* o = rays_od + 6 * r; const float* d = o + 3;
+        const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+        std::vector<int32_t> leaves2, leaves4, st;
+        st.push_back(bvh.root);
+        while (!st.empty()) {
+            int32_t c = st.back(); st.pop_back();
+            if (c < 0) { leaves2.push_back(c); continue; }
+            const DevNode& n = bvh.nodes[(size_t)c];
+            for (int k = 0; k < 2; ++k) { float lo[3] = {n.bx[k], n.by[k], n.bz[k]}, hi[3] = {n.bx[2 + k], n.by[2 + k], n.bz[2 + k]}; if (slab(lo, hi, o, inv)) st.push_back(n.child[k]); }
+        }
+        st.push_back(root4);
+        size_t deepest = 0;
+        while (!st.empty()) {
+            deepest = std::max(deepest, st.size());
+            int32_t c = st.back(); st.pop_back();
+            if (c < 0) { leaves4.push_back(c); continue; }
+            const DevNode4& n = n4[(size_t)c];
+            for (int k = 0; k < 4; ++k) { float lo[3] = {n.lox[k], n.loy[k], n.loz[k]}, hi[3] = {n.hix[k], n.hiy[k], n.hiz[k]}; if (slab(lo, hi, o, inv)) st.push_back(n.child[k]); }
+        }
+        std::sort(leaves2.begin(), leaves2.end()); std::sort(leaves4.begin(), leaves4.end());
+        if (leaves2 != leaves4) ++mism;
+    }
+    if (out_mismatch) *out_mismatch = mism;
     return MI355PT_OK;
 }
 

@@ -137,4 +137,102 @@ void build_bvh(const std::vector<BuildTri>& tris, BvhOut* out) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// BVH2 -> BVH4 (layout.hpp DevNode4).  `budget` = stack slots still free below this node; expanding a child into its two children makes the
+// node one wider, i.e. costs one more slot for every subtree below it, and is allowed only while each member's all-binary height still fits.
+namespace {
+struct Collapse4 {
+    const std::vector<DevNode>& n2;
+    std::vector<DevNode4>& out;
+    std::vector<int> height;      // all-binary height of each BVH2 node's subtree (leaf = 0)
+    int height_of(int32_t link) const { return link < 0 ? 0 : height[(size_t)link]; }
+    int compute_height(int32_t link) {
+        if (link < 0) return 0;
+        int h = 1 + std::max(compute_height(n2[(size_t)link].child[0]), compute_height(n2[(size_t)link].child[1]));
+        height[(size_t)link] = h;
+        return h;
+    }
+    struct Member { float lo[3], hi[3]; int32_t link; };
+    static Member member(const DevNode& n, int c) {
+        return Member{{n.bx[c], n.by[c], n.bz[c]}, {n.bx[2 + c], n.by[2 + c], n.bz[2 + c]}, n.child[c]};
+    }
+    static float area(const Member& m) {
+        float d[3] = {m.hi[0] - m.lo[0], m.hi[1] - m.lo[1], m.hi[2] - m.lo[2]};
+        return d[0] < 0 ? 0.0f : 2.0f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+    int32_t emit(int32_t link2, int budget) {
+        if (link2 < 0) return link2;
+        std::vector<Member> m = {member(n2[(size_t)link2], 0), member(n2[(size_t)link2], 1)};
+        while (m.size() < 4) {
+            // widest-area internal member whose expansion keeps every member inside the slots that remain with one more sibling pending
+            int best = -1;
+            for (size_t i = 0; i < m.size(); ++i) {
+                if (m[i].link < 0) continue;
+                const DevNode& e = n2[(size_t)m[i].link];
+                bool fits = true;
+                const int left = budget - (int)m.size();                 // slots below a node of m.size() + 1 children
+                for (size_t j = 0; j < m.size() && fits; ++j) if (j != i && height_of(m[j].link) > left) fits = false;
+                if (height_of(e.child[0]) > left || height_of(e.child[1]) > left) fits = false;
+                if (fits && (best < 0 || area(m[i]) > area(m[(size_t)best]))) best = (int)i;
+            }
+            if (best < 0) break;
+            const DevNode& e = n2[(size_t)m[(size_t)best].link];
+            Member a = member(e, 0), b = member(e, 1);
+            m[(size_t)best] = a; m.push_back(b);
+        }
+        const size_t idx = out.size();
+        out.emplace_back();
+        const int below = budget - ((int)m.size() - 1);
+        int32_t links[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < m.size(); ++i) links[i] = emit(m[i].link, below);
+        DevNode4& d = out[idx];
+        for (int c = 0; c < 4; ++c) {
+            const bool used = (size_t)c < m.size();
+            // an unused slot is a point box at +FLT_MAX: the slab test misses it for every finite ray (an INVERTED infinite box would be hit by
+            // every ray: min(lo, hi) = -inf, max = +inf), like the empty second child of the wrapped single-leaf root in bvh_builder.cpp
+            d.lox[c] = used ? m[(size_t)c].lo[0] : FLT_MAX; d.loy[c] = used ? m[(size_t)c].lo[1] : FLT_MAX; d.loz[c] = used ? m[(size_t)c].lo[2] : FLT_MAX;
+            d.hix[c] = used ? m[(size_t)c].hi[0] : FLT_MAX; d.hiy[c] = used ? m[(size_t)c].hi[1] : FLT_MAX; d.hiz[c] = used ? m[(size_t)c].hi[2] : FLT_MAX;
+            d.child[c] = used ? links[c] : 0; d.pad[c] = 0;
+        }
+        return (int32_t)idx;
+    }
+};
+}  // namespace
+
+bool collapse_bvh4(const std::vector<DevNode>& nodes2, int32_t root2, size_t n_tris, std::vector<DevNode4>* nodes4, int32_t* root4, int* max_stack,
+                   std::string* err) {
+    nodes4->clear();
+    nodes4->reserve(nodes2.size() / 2 + 1);
+    Collapse4 col{nodes2, *nodes4, std::vector<int>(nodes2.size(), 0)};
+    col.compute_height(root2);
+    if (root2 < 0 || col.height_of(root2) >= STACK_DEPTH) { *err = "BVH deeper than the traversal stack"; return false; }
+    *root4 = col.emit(root2, STACK_DEPTH - 1);
+    // the guarantees the kernel relies on, checked on the tree that is uploaded: links in range, no cycle, every triangle in exactly one
+    // leaf, worst-case pending siblings along any path (= the per-lane LDS stack need) below STACK_DEPTH
+    size_t tris_seen = 0, visited = 0;
+    bool ok = *root4 >= 0 && (size_t)*root4 < nodes4->size();
+    int worst = 0;
+    std::vector<std::pair<int32_t, int>> todo;            // (node, stack slots in use on arrival)
+    if (ok) todo.push_back({*root4, 0});
+    while (ok && !todo.empty()) {
+        const int32_t ni = todo.back().first; const int used = todo.back().second; todo.pop_back();
+        if (++visited > nodes4->size()) { ok = false; break; }
+        const DevNode4& nd = (*nodes4)[(size_t)ni];
+        int k = 0;
+        for (int c = 0; c < 4; ++c) if (nd.lox[c] <= nd.hix[c] && nd.lox[c] < FLT_MAX) ++k;
+        if (k < 1 || used + (k - 1) >= STACK_DEPTH) { ok = false; break; }
+        worst = std::max(worst, used + (k - 1));
+        for (int c = 0; c < 4; ++c) {
+            if (!(nd.lox[c] <= nd.hix[c] && nd.lox[c] < FLT_MAX)) continue;
+            const int32_t l = nd.child[c];
+            if (l < 0) { const uint32_t f = leaf_first(l), n = leaf_count(l); if ((size_t)f + n > n_tris) ok = false; tris_seen += n; }
+            else if ((size_t)l >= nodes4->size()) ok = false;
+            else todo.push_back({l, used + (k - 1)});
+        }
+    }
+    if (!ok || tris_seen != n_tris) { *err = "internal error: collapsed BVH failed validation"; return false; }
+    *max_stack = worst;
+    return true;
+}
+
 }  // namespace pt

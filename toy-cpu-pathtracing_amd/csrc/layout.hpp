@@ -41,6 +41,17 @@ struct alignas(16) DevNode {
     uint32_t pad[2];
 };
 static_assert(sizeof(DevNode) == 64, "node must be 64 B");
+// The tree the wave-cooperative traversals walk: the BVH2 collapsed to up to FOUR children per node (scene.cpp collapse_bvh4).  A wave's
+// node steps per ray are bounded below by the depth of the path it follows (stealing spreads the breadth of a traversal over idle lanes, not
+// its depth): 18 steps for rays that need 10 on average in the BVH2.  Half the levels = half the dependent fetch -> test -> fetch round trips.
+// Children are collapsed only where the per-lane LDS stack (STACK_DEPTH entries) provably cannot overflow: a node with k children
+// leaves at most k - 1 pending siblings per level, and a subtree is collapsed only if the slots left cover its all-binary height.
+struct alignas(16) DevNode4 {
+    float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];   // child c box: lo = (lox[c], loy[c], loz[c]), hi likewise; unused slots: a point box at +FLT_MAX (never hit)
+    int32_t child[4];                                       // >= 0: DevNode4 index; < 0: leaf (leaf_first / leaf_count)
+    uint32_t pad[4];
+};
+static_assert(sizeof(DevNode4) == 128, "wide node must be 128 B");
 PT_HD inline int32_t make_leaf(uint32_t first, uint32_t count) { return (int32_t)(0x80000000u | (first << 3) | (count - 1)); }
 PT_HD inline uint32_t leaf_first(int32_t c) { return ((uint32_t)c & 0x7fffffffu) >> 3; }
 PT_HD inline uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1; }
@@ -58,7 +69,7 @@ struct alignas(16) DevTriShade {
     float n2z; float tangent[3];   // LOCAL-space per-triangle tangent (valid if flags & 1)
     float uv0[2]; float uv1[2];
     float uv2[2]; uint32_t material; uint32_t instance;
-    uint32_t flags;                // bit0: has uv/tangent, bit1: emissive
+    uint32_t flags;                // bit0: has uv/tangent, bit1: emissive, bit2: instance transform has an identity linear part
     uint32_t light;                // light index if emissive else ~0
     uint32_t local_tri;            // triangle index inside its mesh
     float light_pdf_area;          // (1/area_i) * (cdf_i - cdf_{i-1}) for emissive tris (emissive_triangle_mesh.rs:334-353)
@@ -145,7 +156,8 @@ struct DevEnv {
 };
 
 struct DevScene {
-    const DevNode* nodes;
+    const DevNode* nodes;         // BVH2: the plain traversals (probes, canonical step counts)
+    const DevNode4* nodes4;       // the same tree collapsed to <= 4 children per node: the render path's cooperative traversals
     const DevTri* tris;
     const DevTriShade* shade;
     const DevInstance* instances;
@@ -162,7 +174,8 @@ struct DevScene {
     const float* cc_albedo;       // [n clearcoat materials][64] E(cos theta) of the coat's directional albedo (mi355pt_params.albedo_lut)
     uint32_t n_nodes, n_tris, n_lights, n_materials;
     int32_t root;                 // root link (node index, or leaf if the scene has <= MAX_LEAF_TRIS tris)
-    uint32_t pad[3];
+    int32_t root4;                // root of nodes4
+    uint32_t n_nodes4, pad1;
     const DevEnv* envs;           // every infinite light of the scene (Scene sums them all: scene.rs:185-231)
     uint32_t n_envs, pad_env;
 };
@@ -194,7 +207,10 @@ struct DevParams {
 
 // Scene feature bits: the host picks the smallest kernel specialisation that covers the scene's materials, so a
 // Lambert-only Cornell box does not carry the registers and code of the clearcoat / dielectric / texture paths.
-enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_METAL = 32, FEAT_DELTA = 64, FEAT_ENV = 128, FEAT_ALL = 255 };
+// FEAT_EMTEX: a textured emitter (radiance looked up at the hit / sampled uv) — its own bit so that textured SURFACES (scene 3, the headline
+// config) do not carry the emitter-texture code in their register budget; FEAT_STD = every feature but that one.
+enum : uint32_t { FEAT_TEX = 1, FEAT_DIEL = 2, FEAT_CC = 4, FEAT_MLIGHT = 8, FEAT_ROUGH = 16, FEAT_METAL = 32, FEAT_DELTA = 64, FEAT_ENV = 128, FEAT_EMTEX = 256,
+                  FEAT_STD = 255, FEAT_ALL = 511 };
 
 struct DevStats {
     unsigned long long samples, closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow;

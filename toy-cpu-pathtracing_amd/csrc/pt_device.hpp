@@ -207,16 +207,18 @@ PT_DEV float random_next(Sampler& s) {
     uint64_t h = mix_bits(key + 0x632be59bd9b4e019ull * (uint64_t)(++s.dimension));
     return (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f;
 }
+// (the murmur(dimension, seed) word is fetched BEFORE the digit loop of sampler_index: it does not depend on it, and its L1 round trip
+// then overlaps the ~250 instructions of the loop instead of following them)
 PT_DEV uint32_t get_1d_bits(Sampler& s, const SamplerCtx& c) {           // :203-213
+    const uint64_t h = dim_hash(c, s.dimension + 1u);
     uint64_t si = sampler_index(s, c);
     s.dimension += 1;
-    uint64_t h = dim_hash(c, s.dimension);
     return fast_owen(sobol_dim0(si), (uint32_t)h);
 }
 PT_DEV void get_2d_bits(Sampler& s, const SamplerCtx& c, uint32_t& b0, uint32_t& b1) {   // :215-230
+    const uint64_t h = dim_hash(c, s.dimension + 2u);
     uint64_t si = sampler_index(s, c);
     s.dimension += 2;
-    uint64_t h = dim_hash(c, s.dimension);
     b0 = fast_owen(sobol_dim0(si), (uint32_t)h);
     b1 = fast_owen(sobol_dim1(si), (uint32_t)(h >> 32));
 }
@@ -319,13 +321,16 @@ PT_DEV void rgb2spec_lookup(const DevScene& sc, const float enc[3], float c[3]) 
     float dx = x - (float)xi, dy = y - (float)yi, dz = (z - zn0) / (zn1 - zn0);
     const float4* tab = (const float4*)sc.rgb2spec;
     size_t base = (((size_t)mc * 64 + zi) * 64 + yi) * 64 + xi;
-    float4 c000 = tab[base], c100 = tab[base + 1], c010 = tab[base + 64], c110 = tab[base + 65];
-    float4 c001 = tab[base + 4096], c101 = tab[base + 4097], c011 = tab[base + 4160], c111 = tab[base + 4161];
+    // trilinear in the order of the reference (x, then y, then z: rgb_sigmoid_polynomial.rs:140-152), one x-pair of cells at a time: eight
+    // float4 cells live at once were the register peak of the textured kernels
 #define PT_LERP(a, b, t) ((a) + ((b) - (a)) * (t))
-#define PT_TRI(m) PT_LERP(PT_LERP(PT_LERP(c000.m, c100.m, dx), PT_LERP(c010.m, c110.m, dx), dy), \
-                          PT_LERP(PT_LERP(c001.m, c101.m, dx), PT_LERP(c011.m, c111.m, dx), dy), dz)
-    c[0] = PT_TRI(x); c[1] = PT_TRI(y); c[2] = PT_TRI(z);
-#undef PT_TRI
+    float r00[3], r10[3], r01[3], r11[3];
+    { const float4 a = tab[base], b = tab[base + 1]; r00[0] = PT_LERP(a.x, b.x, dx); r00[1] = PT_LERP(a.y, b.y, dx); r00[2] = PT_LERP(a.z, b.z, dx); }
+    { const float4 a = tab[base + 64], b = tab[base + 65]; r10[0] = PT_LERP(a.x, b.x, dx); r10[1] = PT_LERP(a.y, b.y, dx); r10[2] = PT_LERP(a.z, b.z, dx); }
+    { const float4 a = tab[base + 4096], b = tab[base + 4097]; r01[0] = PT_LERP(a.x, b.x, dx); r01[1] = PT_LERP(a.y, b.y, dx); r01[2] = PT_LERP(a.z, b.z, dx); }
+    { const float4 a = tab[base + 4160], b = tab[base + 4161]; r11[0] = PT_LERP(a.x, b.x, dx); r11[1] = PT_LERP(a.y, b.y, dx); r11[2] = PT_LERP(a.z, b.z, dx); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = PT_LERP(PT_LERP(r00[k], r10[k], dy), PT_LERP(r01[k], r11[k], dy), dz);
 #undef PT_LERP
 }
 
@@ -532,6 +537,39 @@ PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* s
     return false;
 }
 
+// One step through the collapsed tree (layout.hpp DevNode4): slab tests of up to four child boxes.  n[c] = entry distance of child c, or
+// +inf if the ray misses it (unused slots hold an inverted infinite box and miss by themselves).
+struct Node4Hits { float n[4]; int32_t link[4]; };
+PT_DEV Node4Hits node4_step(const DevNode4* nodes, int32_t cur, f3 ro, f3 inv, float t_lim) {
+    const float4* q = (const float4*)(nodes + cur);
+    // axis by axis: the interval of each child narrows as its x, y, z slabs arrive (max / min are exact, so the order does not change a
+    // result); two float4 of planes are live at a time instead of six — the traversal loop sits inside the register budget of the path state
+    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f, f0 = t_lim, f1 = t_lim, f2 = t_lim, f3_ = t_lim;
+#define PT_AXIS4(LO, HI, O, I)                                                                                              \
+    {                                                                                                                       \
+        const float4 lo = q[LO], hi = q[HI];                                                                                \
+        float l, h;                                                                                                         \
+        l = (lo.x - O) * I; h = (hi.x - O) * I; n0 = fmaxf(n0, fminf(l, h)); f0 = fminf(f0, fmaxf(l, h));                    \
+        l = (lo.y - O) * I; h = (hi.y - O) * I; n1 = fmaxf(n1, fminf(l, h)); f1 = fminf(f1, fmaxf(l, h));                    \
+        l = (lo.z - O) * I; h = (hi.z - O) * I; n2 = fmaxf(n2, fminf(l, h)); f2 = fminf(f2, fmaxf(l, h));                    \
+        l = (lo.w - O) * I; h = (hi.w - O) * I; n3 = fmaxf(n3, fminf(l, h)); f3_ = fminf(f3_, fmaxf(l, h));                  \
+    }
+    PT_AXIS4(0, 1, ro.x, inv.x) PT_AXIS4(2, 3, ro.y, inv.y) PT_AXIS4(4, 5, ro.z, inv.z)
+#undef PT_AXIS4
+    const int4 ch = *(const int4*)(q + 6);
+    Node4Hits h;
+    h.n[0] = n0 <= f0 ? n0 : INFINITY; h.n[1] = n1 <= f1 ? n1 : INFINITY; h.n[2] = n2 <= f2 ? n2 : INFINITY; h.n[3] = n3 <= f3_ ? n3 : INFINITY;
+    h.link[0] = ch.x; h.link[1] = ch.y; h.link[2] = ch.z; h.link[3] = ch.w;
+    return h;
+}
+// ascending by entry distance (5 compare-exchanges); misses (+inf) end up last
+PT_DEV void sort4(Node4Hits& h) {
+#define PT_CSWAP(a, b) { const bool s = h.n[b] < h.n[a]; const float tn = s ? h.n[b] : h.n[a]; const float tx = s ? h.n[a] : h.n[b]; \
+                         const int32_t ln = s ? h.link[b] : h.link[a]; const int32_t lx = s ? h.link[a] : h.link[b]; h.n[a] = tn; h.n[b] = tx; h.link[a] = ln; h.link[b] = lx; }
+    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+}
+
 // Any hit with DEFERRED, DENSE triangle tests (wave-cooperative; every lane of the wave must call it, `want` = this lane has
 // a ray).  In the plain loop above a wave spends most of its any-hit VALU time on triangle steps executed for the one or
 // two straggler lanes that happen to sit in a leaf (measured: 24 triangle steps per wave iteration at 3.7 % lane use).
@@ -548,10 +586,13 @@ struct AnyLds { uint32_t* ring; uint32_t* occl; uint32_t* pair; };   // ring[ANY
 #ifndef PT_STEAL_EVERY
 #define PT_STEAL_EVERY 1u
 #endif
+#ifndef PT_STEAL_EVERY_CLOSEST
+#define PT_STEAL_EVERY_CLOSEST 1u
+#endif
 #ifndef PT_STEAL_MAX_ACTIVE
 #define PT_STEAL_MAX_ACTIVE 52
 #endif
-template <bool STATS>
+template <bool STATS, bool WIDE>
 PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bool want, uint32_t* stack, uint32_t lane, const AnyLds& L,
                                StatCounters& st) {
     if (!want) { rd = mk3(0.0f, 0.0f, 1.0f); ro = mk3(0.0f, 0.0f, 0.0f); t_max = 0.0f; }
@@ -560,9 +601,11 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
     if (lane < 2) L.occl[lane] = 0u;
     __syncthreads();
     // the ray this lane is WALKING (its own, or one it is helping with) — the lane's own ray stays in ro/rd/rs for the flushes
-    f3 w_ro = ro, w_inv = rs.inv; float w_tmax = t_max; uint32_t owner = lane;
-    int sp = 0, sb = 0;                       // this lane's LDS stack holds [sb, sp): pops come off the top, steals off the bottom
-    int32_t cur = sc.root;
+    // (box tests only see distances up to 1e30: the unused slots of a DevNode4 are point boxes at FLT_MAX, whose slab distance FLT_MAX / |d|
+    // must never fall inside [0, t_lim] — an unbounded shadow ray (t_max = FLT_MAX, directional and environment lights) would let it)
+    f3 w_ro = ro, w_inv = rs.inv; float w_tmax = fminf(t_max, 1e30f); uint32_t owner = lane;
+    int sp = 0, sb = 0;
+    int32_t cur = WIDE ? sc.root4 : sc.root;
     uint32_t leaf_off = 0;                    // triangles of the current leaf already queued
     bool done = !want;
     uint32_t head = 0, tail = 0;              // wave-uniform ring cursors
@@ -592,26 +635,43 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
 
     for (;;) {
         if (!done && cur >= 0) {
-            const float4* q = (const float4*)(sc.nodes + cur);
-            float4 nx = q[0], ny = q[1], nz = q[2];
-            int2 ch = *(const int2*)(q + 3);
-            if (STATS) { st.nodes_shadow++; if (wave_leader()) st.w[2]++; }
-            float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
-            float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
-            float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;
-            float l1y = (ny.y - w_ro.y) * w_inv.y, h1y = (ny.w - w_ro.y) * w_inv.y;
-            float l0z = (nz.x - w_ro.z) * w_inv.z, h0z = (nz.z - w_ro.z) * w_inv.z;
-            float l1z = (nz.y - w_ro.z) * w_inv.z, h1z = (nz.w - w_ro.z) * w_inv.z;
-            float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
-            float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), w_tmax));
-            float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
-            float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), w_tmax));
-            bool hit0 = n0 <= f0, hit1 = n1 <= f1;
-            if (hit0 && hit1) { stack[sp * 64] = (uint32_t)ch.y; ++sp; cur = ch.x; }
-            else if (hit0) cur = ch.x;
-            else if (hit1) cur = ch.y;
-            else if (sp == sb) done = true;
-            else { --sp; cur = (int32_t)stack[sp * 64]; }
+            if constexpr (WIDE) {
+                if (STATS) { st.nodes_shadow++; if (wave_leader()) st.w[2]++; }
+                const Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_tmax);
+                // any-hit needs no order: continue into the first child hit, queue the others
+                int32_t nxt = 0; bool have = false;
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (h.n[c] < INFINITY) {
+                        if (!have) { have = true; nxt = h.link[c]; }
+                        else { stack[sp * 64] = (uint32_t)h.link[c]; ++sp; }
+                    }
+                }
+                if (have) cur = nxt;
+                else if (sp == sb) done = true;
+                else { --sp; cur = (int32_t)stack[sp * 64]; }
+            } else {
+                const float4* q = (const float4*)(sc.nodes + cur);
+                float4 nx = q[0], ny = q[1], nz = q[2];
+                int2 ch = *(const int2*)(q + 3);
+                if (STATS) { st.nodes_shadow++; if (wave_leader()) st.w[2]++; }
+                float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
+                float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
+                float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;
+                float l1y = (ny.y - w_ro.y) * w_inv.y, h1y = (ny.w - w_ro.y) * w_inv.y;
+                float l0z = (nz.x - w_ro.z) * w_inv.z, h0z = (nz.z - w_ro.z) * w_inv.z;
+                float l1z = (nz.y - w_ro.z) * w_inv.z, h1z = (nz.w - w_ro.z) * w_inv.z;
+                float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+                float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), w_tmax));
+                float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+                float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), w_tmax));
+                bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+                if (hit0 && hit1) { stack[sp * 64] = (uint32_t)ch.y; ++sp; cur = ch.x; }
+                else if (hit0) cur = ch.x;
+                else if (hit1) cur = ch.y;
+                else if (sp == sb) done = true;
+                else { --sp; cur = (int32_t)stack[sp * 64]; }
+            }
         }
         // lanes sitting in a leaf queue up to two of its triangles per step, then move on
         const bool at_leaf = !done && cur < 0;
@@ -684,7 +744,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
 #endif
 struct ClosestLds { uint32_t* ring; unsigned long long* best; uint32_t* pair; };   // ring[ANY_RING], best[64], pair[64]
 
-template <bool STATS>
+template <bool STATS, bool WIDE>
 PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint32_t* stack, uint32_t lane, const ClosestLds& L, Hit& hit,
                                StatCounters& st) {
     if (!want) { rd = mk3(0.0f, 0.0f, 1.0f); ro = mk3(0.0f, 0.0f, 0.0f); }
@@ -692,12 +752,13 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
     const uint32_t kpack = (uint32_t)rs.kx | ((uint32_t)rs.ky << 2) | ((uint32_t)rs.kz << 4);
     L.best[lane] = (0x7f7fffffull << 32) | 0xffffffffull;                 // (FLT_MAX, no triangle)
     __syncthreads();
-    f3 w_ro = ro, w_inv = rs.inv; float w_tbest = 3.402823466e+38f; uint32_t owner = lane;
+    f3 w_ro = ro, w_inv = rs.inv; float w_tbest = 1e30f; uint32_t owner = lane;             // box-test limit, see trace_any_deferred
     int sp = 0, sb = 0;
-    int32_t cur = sc.root;
+    int32_t cur = WIDE ? sc.root4 : sc.root;
     uint32_t leaf_off = 0;
     bool done = !want;
     uint32_t head = 0, tail = 0;
+    uint32_t since_steal = 0u;
     if (STATS && want) st.closest_rays++;
 
     auto flush = [&](uint32_t n) {
@@ -723,29 +784,42 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
 
     for (;;) {
         if (!done && cur >= 0) {
-            const float4* q = (const float4*)(sc.nodes + cur);
-            float4 nx = q[0], ny = q[1], nz = q[2];
-            int2 ch = *(const int2*)(q + 3);
-            if (STATS) { st.nodes_closest++; if (wave_leader()) st.w[0]++; }
-            float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
-            float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
-            float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;
-            float l1y = (ny.y - w_ro.y) * w_inv.y, h1y = (ny.w - w_ro.y) * w_inv.y;
-            float l0z = (nz.x - w_ro.z) * w_inv.z, h0z = (nz.z - w_ro.z) * w_inv.z;
-            float l1z = (nz.y - w_ro.z) * w_inv.z, h1z = (nz.w - w_ro.z) * w_inv.z;
-            float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
-            float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), w_tbest));
-            float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
-            float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), w_tbest));
-            bool hit0 = n0 <= f0, hit1 = n1 <= f1;
-            if (hit0 && hit1) {
-                bool first0 = n0 <= n1;
-                stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp;
-                cur = first0 ? ch.x : ch.y;
-            } else if (hit0) cur = ch.x;
-            else if (hit1) cur = ch.y;
-            else if (sp == sb) done = true;
-            else { --sp; cur = (int32_t)stack[sp * 64]; }
+            if constexpr (WIDE) {
+                if (STATS) { st.nodes_closest++; if (wave_leader()) st.w[0]++; }
+                Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_tbest);
+                sort4(h);
+                // nearest child next; the others go to the stack farthest first, so that the nearer of them is popped first
+                if (h.n[3] < INFINITY) { stack[sp * 64] = (uint32_t)h.link[3]; ++sp; }
+                if (h.n[2] < INFINITY) { stack[sp * 64] = (uint32_t)h.link[2]; ++sp; }
+                if (h.n[1] < INFINITY) { stack[sp * 64] = (uint32_t)h.link[1]; ++sp; }
+                if (h.n[0] < INFINITY) cur = h.link[0];
+                else if (sp == sb) done = true;
+                else { --sp; cur = (int32_t)stack[sp * 64]; }
+            } else {
+                const float4* q = (const float4*)(sc.nodes + cur);
+                float4 nx = q[0], ny = q[1], nz = q[2];
+                int2 ch = *(const int2*)(q + 3);
+                if (STATS) { st.nodes_closest++; if (wave_leader()) st.w[0]++; }
+                float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
+                float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
+                float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;
+                float l1y = (ny.y - w_ro.y) * w_inv.y, h1y = (ny.w - w_ro.y) * w_inv.y;
+                float l0z = (nz.x - w_ro.z) * w_inv.z, h0z = (nz.z - w_ro.z) * w_inv.z;
+                float l1z = (nz.y - w_ro.z) * w_inv.z, h1z = (nz.w - w_ro.z) * w_inv.z;
+                float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+                float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), w_tbest));
+                float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+                float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), w_tbest));
+                bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+                if (hit0 && hit1) {
+                    bool first0 = n0 <= n1;
+                    stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp;
+                    cur = first0 ? ch.x : ch.y;
+                } else if (hit0) cur = ch.x;
+                else if (hit1) cur = ch.y;
+                else if (sp == sb) done = true;
+                else { --sp; cur = (int32_t)stack[sp * 64]; }
+            }
         }
         const bool at_leaf = !done && cur < 0;
         const unsigned long long m1 = __ballot(at_leaf);
@@ -770,9 +844,10 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
         const unsigned long long m_act = __ballot(!done);
         if (m_act == 0ull) break;
 #if PT_ANY_STEAL
-        if (__popcll(m_act) <= PT_STEAL_MAX_ACTIVE) {
+        if (++since_steal >= PT_STEAL_EVERY_CLOSEST && __popcll(m_act) <= PT_STEAL_MAX_ACTIVE) {
             const unsigned long long m_donor = __ballot(!done && sp > sb);
             if (m_donor != 0ull) {
+                since_steal = 0u;
                 const unsigned long long m_idle = ~m_act;
                 const unsigned long long below = (1ull << lane) - 1ull;
                 const uint32_t n_pairs = min((uint32_t)__popcll(m_donor), (uint32_t)__popcll(m_idle));

@@ -58,6 +58,13 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 // MODE compiles the renderer strategy and the sampler in (MODE_GENERIC reads them from DevParams): the branches on
 // prm.strategy / the sampler mode fold away, worth +2.5 % on C2 (MIS + Sobol), +1.3 % on C5 (NEE + Sobol).
 enum : uint32_t { MODE_GENERIC = 0, MODE_MIS_SOBOL = 1, MODE_NEE_SOBOL = 2 };
+// Which tree the cooperative traversals walk (both are on the device).  The 4-wide tree halves the dependent node round trips per ray
+// (18 -> ~10 wave steps per closest-hit trace) and is worth +3...4.5 % — except in the kernel specialised for textured Lambert scenes
+// (FEAT_TEX alone: C2's kernel), where the wider node step's registers push the shading phase from 108 to 132 B of scratch per lane and
+// the same tree costs 4 % (same-box A/B: scene 3 1 467 vs 1 526, scenes 4 / 5 alike; scene 0 — the SAME geometry without textures —
+// 1 791 vs 1 721, scene 8 1 498 vs 1 434, scene 10 1 491 vs 1 429, scene 17 1 056 vs 1 025).  Measured per kernel, like every
+// register-budget decision here.
+template <uint32_t FEAT> constexpr bool wide_bvh() { return FEAT != FEAT_TEX; }
 template <bool STATS, uint32_t FEAT, uint32_t MODE = MODE_GENERIC>
 __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WAVES)) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm_in, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, float* __restrict__ partial, unsigned* __restrict__ work_counter,
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             bool got = false;
 #if PT_CLOSEST_COOP
             if (STATS && prm.stats_mode == 1u) { if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st); }
-            else got = trace_closest_coop<STATS>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st);
+            else got = trace_closest_coop<STATS, wide_bvh<FEAT>()>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st);
 #else
             if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st);
 #endif
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 if (STATS && sh.on) st.w[6]++;
                 bool occluded = false;
                 if (STATS && prm.stats_mode == 1u) { if (sh.on) occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st); }
-                else occluded = trace_any_deferred<STATS>(sc, sh.o, sh.d, sh.t, sh.on, stack, lane, any_lds, st);
+                else occluded = trace_any_deferred<STATS, wide_bvh<FEAT>()>(sc, sh.o, sh.d, sh.t, sh.on, stack, lane, any_lds, st);
                 if (sh.on && !occluded) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
 
 // ---- launch of the production variants of one MODE: smallest compiled feature set covering `feat` ----
 inline uint32_t pick_features(uint32_t feat) {
-    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_METAL, FEAT_DIEL | FEAT_ROUGH, FEAT_DELTA | FEAT_MLIGHT, FEAT_CC, FEAT_CC | FEAT_TEX, FEAT_ALL & ~FEAT_CC, FEAT_ALL};
+    const uint32_t sets[] = {0u, FEAT_TEX, FEAT_DIEL, FEAT_METAL, FEAT_DIEL | FEAT_ROUGH, FEAT_DELTA | FEAT_MLIGHT, FEAT_CC, FEAT_CC | FEAT_TEX, FEAT_STD & ~FEAT_CC, FEAT_STD, FEAT_ALL};
     for (uint32_t s : sets) if ((feat & ~s) == 0u) return s;
     return FEAT_ALL;
 }
@@ -261,7 +268,7 @@ struct PtLaunchArgs {
     int grid; hipStream_t stream; PathOut pout;
 };
 #define PT_FOR_EACH_FEATURE_SET(X) \
-    X(0u) X(FEAT_TEX) X(FEAT_DIEL) X(FEAT_METAL) X(FEAT_DIEL | FEAT_ROUGH) X(FEAT_DELTA | FEAT_MLIGHT) X(FEAT_CC) X(FEAT_CC | FEAT_TEX) X(FEAT_ALL & ~FEAT_CC) X(FEAT_ALL)
+    X(0u) X(FEAT_TEX) X(FEAT_DIEL) X(FEAT_METAL) X(FEAT_DIEL | FEAT_ROUGH) X(FEAT_DELTA | FEAT_MLIGHT) X(FEAT_CC) X(FEAT_CC | FEAT_TEX) X(FEAT_STD & ~FEAT_CC) X(FEAT_STD) X(FEAT_ALL)
 template <uint32_t MODE>
 void launch_pt_mode(const PtLaunchArgs& a, uint32_t feat) {
     switch (pick_features(feat)) {

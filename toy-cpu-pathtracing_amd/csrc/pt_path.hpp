@@ -65,7 +65,7 @@ PT_DEV Surface load_surface(const DevScene& sc, const Hit& h) {
         tg_l = generate_tangent(sn_l);
     }
     const DevInstance* di = sc.instances + inst;
-    if (di->identity) {
+    if (s.flags & 4u) {                                                              // identity linear part: known from the shade record, no dependent load
         s.ns = normalize(sn_l); s.tangent = tg_l;
     } else {
         s.ns = normalize(mat3_mul(di->nrm, sn_l));
@@ -278,7 +278,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
@@ -290,7 +290,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
@@ -312,7 +312,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
         float Le[4] = {0, 0, 0, 0};
         if (emissive) {                                                      // evaluate_emissive_surface :54-73
             DevSpectrum rs = load_spectrum(&mat->color);
-            eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, rs, wl, sf.uv, Le, st);
+            eval_spectrum<STATS, (FEAT & FEAT_EMTEX) != 0>(sc, rs, wl, sf.uv, Le, st);
             float inten = mat->intensity;
 #pragma unroll
             for (int i = 0; i < 4; ++i) Le[i] = Le[i] * inten;
@@ -336,7 +336,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         // texture, whose phi is taken at uv (0.5, 0.5) (EmissiveMaterial::average_intensity, emissive_material.rs:61-79)
                         float sum = 0.0f;
                         float area = sc.lights[0].area_sum;
-                        if ((FEAT & FEAT_TEX) && mat->color.kind == SPK_TEXTURE) {
+                        if ((FEAT & FEAT_EMTEX) && mat->color.kind == SPK_TEXTURE) {
                             float ph[4];
                             DevSpectrum ls = load_spectrum(&mat->color);
                             eval_spectrum<false, true>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
@@ -353,7 +353,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float inten = lm->intensity;
                         float sum = 0.0f;
 #pragma unroll
@@ -785,7 +785,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
                     DevSpectrum ls0 = load_spectrum(&lm0->color);
                     // (a textured radiance: phi at uv (0.5, 0.5), emissive_material.rs:61-79; the radiance itself follows at the sampled point)
-                    eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, ls0, wl, f2{0.5f, 0.5f}, lrad, st);
+                    eval_spectrum<STATS, (FEAT & FEAT_EMTEX) != 0>(sc, ls0, wl, f2{0.5f, 0.5f}, lrad, st);
                     float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
@@ -796,7 +796,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
@@ -809,7 +809,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_TEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
@@ -865,7 +865,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
                     float b2 = 1.0f - b0 - b1;
                     f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
-                    if ((FEAT & FEAT_TEX) && lm->color.kind == SPK_TEXTURE) {      // EmissiveMaterial::radiance at the sampled point's uv (:48-59, emissive_triangle_mesh.rs:237-247)
+                    if ((FEAT & FEAT_EMTEX) && lm->color.kind == SPK_TEXTURE) {    // EmissiveMaterial::radiance at the sampled point's uv (:48-59, emissive_triangle_mesh.rs:237-247)
                         const float* tu = sc.light_uvs + (size_t)(lt.first_tri + tsel) * 6;
                         const f2 suv = f2{tu[0] * b0 + tu[2] * b1 + tu[4] * b2, tu[1] * b0 + tu[3] * b1 + tu[5] * b2};
                         DevSpectrum lsx = load_spectrum(&lm->color);

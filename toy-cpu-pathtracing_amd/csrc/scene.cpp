@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <cfloat>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -298,7 +299,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             const float* n0 = &mesh.nrm[3 * vi[0]]; const float* n1 = &mesh.nrm[3 * vi[1]]; const float* n2 = &mesh.nrm[3 * vi[2]];
             sh.n0[0] = n0[0]; sh.n0[1] = n0[1]; sh.n0[2] = n0[2]; sh.n1x = n1[0];
             sh.n1yz[0] = n1[1]; sh.n1yz[1] = n1[2]; sh.n2xy[0] = n2[0]; sh.n2xy[1] = n2[1]; sh.n2z = n2[2];
-            sh.flags = 0;
+            sh.flags = di.identity ? 4u : 0u;                                      // bit 2: the instance's linear part is the identity (load_surface)
             if (!mesh.uv.empty()) {
                 sh.flags |= 1u;
                 sh.tangent[0] = mesh.tangent[3 * t]; sh.tangent[1] = mesh.tangent[3 * t + 1]; sh.tangent[2] = mesh.tangent[3 * t + 2];
@@ -448,6 +449,14 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     int rc;
     std::memset(&dev, 0, sizeof(dev));
     if ((rc = upload(this, bvh.nodes, &dev.nodes, err))) return rc;
+    {
+        std::vector<DevNode4> nodes4;
+        int max_stack = 0;
+        if (!collapse_bvh4(bvh.nodes, bvh.root, tris.size(), &nodes4, &dev.root4, &max_stack, err)) return MI355PT_E_INVALID;
+        dev.n_nodes4 = (uint32_t)nodes4.size();
+        if ((rc = upload(this, nodes4, &dev.nodes4, err))) return rc;
+        bvh4_nodes = nodes4.size();
+    }
     if ((rc = upload(this, tris, &dev.tris, err))) return rc;
     if ((rc = upload(this, shade, &dev.shade, err))) return rc;
     if ((rc = upload(this, dinst, &dev.instances, err))) return rc;
@@ -493,13 +502,14 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | ((m.roughness >= 1e-3f || m.roughness_tex != 0xffffffffu) ? FEAT_ROUGH : 0u);
         if (m.type == MT_CLEARCOAT) features |= FEAT_CC;
         if (m.type == MT_METAL) features |= FEAT_METAL;
+        if (m.type == MT_EMISSIVE && m.color.kind == SPK_TEXTURE) features |= FEAT_EMTEX;
         if (m.normal_tex != 0xffffffffu || m.color.kind == SPK_TEXTURE || m.cc_tint.kind == SPK_TEXTURE || m.metallic_tex != 0xffffffffu ||
             m.roughness_tex != 0xffffffffu || m.cc_thickness_tex != 0xffffffffu) features |= FEAT_TEX;
     }
     {
         char tail[128];
         std::snprintf(tail, sizeof(tail), " builder=%s bvh_ms=%.2f bvh_device_ms=%.2f", bvh_builder_used == MI355PT_BVH_GPU ? "gpu" : "host", bvh_build_ms, bvh_device_ms);
-        info = "nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth) + tail;
+        info = "nodes4=" + std::to_string(bvh4_nodes) + " nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth) + tail;
     }
     built = true;
     return MI355PT_OK;

@@ -27,6 +27,9 @@ struct BvhOut {
 };
 // Sweep-SAH BVH2 over triangle bounds; children boxes stored in the parent (layout.hpp DevNode).
 void build_bvh(const std::vector<BuildTri>& tris, BvhOut* out);
+// BVH2 -> BVH4 for the cooperative traversals (layout.hpp DevNode4), with the stack-need guarantee validated; host only (bvh_builder.cpp)
+bool collapse_bvh4(const std::vector<DevNode>& nodes2, int32_t root2, size_t n_tris, std::vector<DevNode4>* nodes4, int32_t* root4, int* max_stack,
+                   std::string* err);
 // SAH constants shared by both builders (env overrides MI355PT_BVH_COST_TRI / MI355PT_BVH_LEAF are for sweeps only)
 void bvh_build_config(float* cost_traverse, float* cost_tri, int* leaf_max);
 // The same contract built on the current HIP device (bvh_gpu.hip): breadth-first binned SAH, one round of launches
@@ -61,6 +64,7 @@ struct SceneImpl {
     std::vector<void*> allocs;
     uint32_t cmf_lut[3] = {0, 0, 0};
     int bvh_depth = 0;
+    size_t bvh4_nodes = 0;        // nodes of the collapsed tree (DevNode4)
     int bvh_builder = 0;          // MI355PT_BVH_AUTO / _HOST / _GPU (mi355pt_scene_set_bvh_builder)
     int bvh_builder_used = 1;     // what build() took
     double bvh_build_ms = 0.0;    // wall time of the BVH build inside build(); bvh_device_ms: device part of a GPU build

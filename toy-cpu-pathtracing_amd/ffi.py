@@ -110,7 +110,7 @@ def _ptr(a, ty):
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
     "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_set_bvh_builder", "scene_build", "render", "render_accum_device", "film_resolve_device",
-    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log", "scene_build_multi", "render_multi", "scene_export_bvh", "coat_albedo_table",
+    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log", "scene_build_multi", "render_multi", "scene_export_bvh", "coat_albedo_table", "probe_bvh_collapse",
     "last_error", "version",
 ]
 
@@ -355,6 +355,15 @@ class Product(Backend):
         nodes = np.zeros((nn.value, 16), np.uint32); tris = np.zeros((nt.value, 12), np.uint32)
         self.check(fn(scene.h, nodes.ctypes.data, C.byref(nn), tris.ctypes.data, C.byref(nt), C.byref(root)), "scene_export_bvh")
         return nodes, tris, root.value
+
+    def probe_bvh_collapse(self, tri_pos, rays_od):
+        """mi355pt_probe_bvh_collapse (host-only) -> (info dict, rays whose leaf sets differ between the BVH2 and the collapsed BVH4)"""
+        tri = np.ascontiguousarray(tri_pos, dtype=np.float32).reshape(-1, 9); rays = np.ascontiguousarray(rays_od, dtype=np.float32).reshape(-1, 6)
+        info = np.zeros(4, np.uint32); mism = C.c_uint32(0)
+        fn = self.lib.mi355pt_probe_bvh_collapse
+        fn.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        self.check(fn(_ptr(tri, C.c_float), tri.shape[0], _ptr(rays, C.c_float), rays.shape[0], _ptr(info, C.c_uint32), C.byref(mism)), "probe_bvh_collapse")
+        return dict(nodes2=int(info[0]), nodes4=int(info[1]), depth2=int(info[2]), max_stack4=int(info[3])), mism.value
 
     def coat_albedo_table(self, alpha, r0):
         """mi355pt_coat_albedo_table: the 64-entry E(cos theta) table behind params.albedo_lut (host-only)."""
