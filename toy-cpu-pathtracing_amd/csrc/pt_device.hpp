@@ -236,19 +236,24 @@ PT_DEV f2 get_2d(Sampler& s, const SamplerCtx& c) {
 // Spectra
 // ---------------------------------------------------------------------------------------------
 struct Wl {                 // SampledWavelengths (sampled_spectrum.rs:304-366)
-    float lam[4];
+    float lam0;             // the hero wavelength; the other three follow from it (wl_lams): one register of path state instead of four
     bool term;              // secondary wavelengths terminated: pdf = {(1/470)/4, 0, 0, 0}
 };
 PT_DEV void wl_init(Wl& w, float u) {
-    w.lam[0] = LAMBDA_MIN + u * (LAMBDA_MAX - LAMBDA_MIN);
+    w.lam0 = LAMBDA_MIN + u * (LAMBDA_MAX - LAMBDA_MIN);
+    w.term = false;
+}
+// new_uniform_range (sampled_spectrum.rs:318-336): lambda_i = lambda_{i-1} + 470/4, wrapped into [360, 830) — the same three additions and
+// wraps every time they are needed, so the values are bit-identical to the stored ones
+PT_DEV void wl_lams(const Wl& w, float lam[4]) {
+    lam[0] = w.lam0;
     const float delta = (LAMBDA_MAX - LAMBDA_MIN) / 4.0f;
 #pragma unroll
     for (int i = 1; i < 4; ++i) {
-        float l = w.lam[i - 1] + delta;
+        float l = lam[i - 1] + delta;
         if (l >= LAMBDA_MAX) l = LAMBDA_MIN + (l - LAMBDA_MAX);
-        w.lam[i] = l;
+        lam[i] = l;
     }
-    w.term = false;
 }
 // sRGB decode of a texture colour (eotf.rs:40-52 has c / 12.92 and ((c + 0.055) / 1.055).powf(2.4)).  The colour only selects
 // rgb2spec coefficients, a continuous map, so the hardware log2 / exp2 (relative error < 1e-6 on this range) replace the ~240 VALU
@@ -356,13 +361,15 @@ PT_DEV void eval_spectrum(const DevScene& sc, const DevSpectrum& sp, const Wl& w
         kind = SPK_SIGMOID;
     }
     const float* lut = sc.luts + (size_t)sp.id * 470;
+    float lam[4];
+    wl_lams(w, lam);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float v;
         if (kind == SPK_CONSTANT) v = c0;
-        else if (kind == SPK_SIGMOID) v = sigmoid_value(c0, c1, c2, w.lam[i]);
-        else if (kind == SPK_ILLUM) v = __uint_as_float(sp.pad[0]) * sigmoid_value(c0, c1, c2, w.lam[i]) * lut_value(lut, w.lam[i]);   // rgb_illuminant_spectrum.rs:44-46
-        else v = lut_value(lut, w.lam[i]);
+        else if (kind == SPK_SIGMOID) v = sigmoid_value(c0, c1, c2, lam[i]);
+        else if (kind == SPK_ILLUM) v = __uint_as_float(sp.pad[0]) * sigmoid_value(c0, c1, c2, lam[i]) * lut_value(lut, lam[i]);   // rgb_illuminant_spectrum.rs:44-46
+        else v = lut_value(lut, lam[i]);
         out[i] = (i > 0 && w.term) ? 0.0f : v;
     }
 }

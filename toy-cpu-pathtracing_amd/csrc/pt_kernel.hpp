@@ -64,7 +64,10 @@ enum : uint32_t { MODE_GENERIC = 0, MODE_MIS_SOBOL = 1, MODE_NEE_SOBOL = 2 };
 // the same tree costs 4 % (same-box A/B: scene 3 1 467 vs 1 526, scenes 4 / 5 alike; scene 0 — the SAME geometry without textures —
 // 1 791 vs 1 721, scene 8 1 498 vs 1 434, scene 10 1 491 vs 1 429, scene 17 1 056 vs 1 025).  Measured per kernel, like every
 // register-budget decision here.
-template <uint32_t FEAT> constexpr bool wide_bvh() { return FEAT != FEAT_TEX; }
+#ifndef PT_WIDE_ALL
+#define PT_WIDE_ALL 0
+#endif
+template <uint32_t FEAT> constexpr bool wide_bvh() { return PT_WIDE_ALL || FEAT != FEAT_TEX; }
 template <bool STATS, uint32_t FEAT, uint32_t MODE = MODE_GENERIC>
 __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WAVES)) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm_in, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, float* __restrict__ partial, unsigned* __restrict__ work_counter,

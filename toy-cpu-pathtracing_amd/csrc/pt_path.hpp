@@ -111,9 +111,11 @@ PT_DEV void env_radiance(const DevScene& sc, const DevEnv& e, f3 dir_render, con
     float enc[3] = {rgb[0] / scale, rgb[1] / scale, rgb[2] / scale}, c[3];
     rgb2spec_lookup(sc, enc, c);
     const float* lut = sc.luts + (size_t)e.illuminant_lut * 470;
+    float lam[4];
+    wl_lams(wl, lam);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float val = (scale * sigmoid_value(c[0], c[1], c[2], wl.lam[i])) * lut_value(lut, wl.lam[i]);
+        float val = (scale * sigmoid_value(c[0], c[1], c[2], lam[i])) * lut_value(lut, lam[i]);
         out[i] = ((i > 0 && wl.term) ? 0.0f : val) * e.intensity;
     }
 }
@@ -1026,7 +1028,9 @@ struct PathOut { float* L; float* lam; float* pdf; uint32_t s_base, n_s; };
 
 PT_DEV void sample_log(const Path& P, const PathOut& pout, size_t slot) {
     const float pdf0 = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
-    float4 l = make_float4(P.L[0], P.L[1], P.L[2], P.L[3]), w = make_float4(P.wl.lam[0], P.wl.lam[1], P.wl.lam[2], P.wl.lam[3]);
+    float lam[4];
+    wl_lams(P.wl, lam);
+    float4 l = make_float4(P.L[0], P.L[1], P.L[2], P.L[3]), w = make_float4(lam[0], lam[1], lam[2], lam[3]);
     float4 q = P.wl.term ? make_float4(pdf0 / 4.0f, 0.0f, 0.0f, 0.0f) : make_float4(pdf0, pdf0, pdf0, pdf0);   // sampled_spectrum.rs:346-365
     ((float4*)pout.L)[slot] = l; ((float4*)pout.lam)[slot] = w; ((float4*)pout.pdf)[slot] = q;
 }
@@ -1037,10 +1041,12 @@ PT_DEV void film_rgb(const Path& P, const DevScene& sc, const DevParams& prm, fl
     const float pdf0 = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
     float X = 0.0f, Y = 0.0f, Z = 0.0f;
     const float4* cmf = (const float4*)sc.cmf;
+    float lam[4];
+    wl_lams(wl, lam);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k == 0 || !wl.term) {
-            int idx = (int)floorf(wl.lam[k] - LAMBDA_MIN);
+            int idx = (int)floorf(lam[k] - LAMBDA_MIN);
             if (idx == 470) idx = 0;
             // sensor.rs:52-66 divides by the wavelength pdf (1/470, or 1/1880 for a terminated sample) and by 4: the pdf is one of two
             // constants, so its reciprocal is folded at compile time (<= 1 ulp from L / pdf)
