@@ -180,14 +180,17 @@ def main():
         if os.path.exists(pv):
             try:
                 vj = json.load(open(pv))
-                if vj.get("workload") == wl and vj.get("library") == prod.version():
+                # the count belongs to a workload; a build other than the profiled one is used too, but flagged (the count moves by a few
+                # per cent between kernel versions, the duration is always live)
+                if vj.get("workload") == wl:
                     ips = vj["SQ_INSTS_VALU_per_launch"] / vj["samples_per_launch"]
                     ach = ips * launch_samples / (avg_ms * 1e-3) / 1e9
                     lane_use = vj["SQ_THREAD_CYCLES_VALU_per_launch"] / (64.0 * vj["SQ_INSTS_VALU_per_launch"])
                     roofline.update({"achieved": round(ach, 1), "frac": round(ach / PEAK_VALU_GINSTR, 4)})
                     roofline["valu"] = {"wave_instr_per_sample": round(ips, 1), "issue_frac": round(ach / PEAK_VALU_GINSTR, 4),
                                         "lane_use": round(lane_use, 4), "useful_lane_frac": round(ach / PEAK_VALU_GINSTR * lane_use, 4),
-                                        "source": "profiles/pmc_valu.json"}
+                                        "source": "profiles/pmc_valu.json", "profiled_library": vj.get("library"),
+                                        "profile_matches_build": vj.get("library") == prod.version()}
             except Exception:
                 pass
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
