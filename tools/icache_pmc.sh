@@ -7,7 +7,7 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "pt_kernel<false, false" in r["Kernel_Name"]:
+        if "pt_kernel<false" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print({k: sum(v) / len(v) for k, v in agg.items()})
 PY

@@ -9,7 +9,7 @@ TU=$1; FEAT=$2; MODE=${3:-0}
 SRC=$R/toy-cpu-pathtracing_amd/csrc/pt_kernels$([ "$TU" = generic ] && echo "" || echo "_$TU").hip
 OUT=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -gline-tables-only -S --cuda-device-only -o $OUT/k.s $SRC 2>/dev/null
-python3 - "$OUT/k.s" "_ZN2pt9pt_kernelILb0ELb0ELj${FEAT}ELj${MODE}EE" "$R/toy-cpu-pathtracing_amd/csrc/" <<'PY'
+python3 - "$OUT/k.s" "_ZN2pt9pt_kernelILb0ELj${FEAT}ELj${MODE}EE" "$R/toy-cpu-pathtracing_amd/csrc/" <<'PY'
 import re, collections, sys, os
 path, sym, srcdir = sys.argv[1:4]
 lines = open(path).read().split('\n')
