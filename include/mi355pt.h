@@ -145,6 +145,16 @@ typedef struct mi355pt_stats {
      * steps, 2 any-hit node steps, 3 any-hit triangle steps, 4 iterations of the wave state machine, 5 lanes shaded
      * (summed over iterations), 6 lanes with a shadow ray, 7 spare */
     uint64_t wave_steps[8];
+    /* diagnostic (collect_stats = 2): how many lanes of the wave were still walking when a node step was issued — wave-level node
+     * steps of the cooperative traversals by busy-lane count, bucket k = 8k+1 .. 8k+8 lanes; [0..7] closest-hit, [8..15] any-hit.  The
+     * low buckets are the tail a lock-step traversal pays for its deepest ray */
+    uint64_t busy_hist[16];
+    /* diagnostic (collect_stats = 2): material divergence of the shading stage, summed over wave iterations — 0 iterations with
+     * at least one lane shading a surface, 1 distinct material classes among those lanes (MI355PT_MAT_* types; the ceiling of what a
+     * material-key sort between bounces could remove is 1 - [0]/[1] of the shading stage), 2 lanes shading a surface, 3 lanes in
+     * the largest class; 4..7 iterations in which the lanes that continue past emission (every class but EMISSIVE) hold 0, 1, 2, >= 3
+     * distinct classes, 8..11 wave-cycles of the shading stage in those iterations (what a second or third class in the wave costs) */
+    uint64_t divergence[12];
 } mi355pt_stats;
 
 /* ---------------- scene construction ---------------- */

@@ -62,4 +62,9 @@ print(json.dumps({"tag": a.tag, "scene": a.scene, "Msamples_s": round(rate, 1), 
                                            "shadow_nodes": round(d["nodes_shadow"] / max(64 * w[2], 1), 3), "shadow_tris": round(d["tris_shadow"] / max(64 * w[3], 1), 3),
                                            "shade": round(w[5] / max(64 * w[4], 1), 3), "shadow_lanes": round(w[6] / max(64 * w[4], 1), 3),
                                            "wave_steps_per_iter": [round(x / max(w[4], 1), 2) for x in w[:4]]})(d["wave_steps"]),
+                  "busy_hist": {k: [round(x / max(sum(h), 1), 3) for x in h] for k, h in zip(("closest", "shadow"), d["busy_hist"])},
+                  "divergence": (lambda v: {"classes_per_iter": round(v[1] / max(v[0], 1), 3), "largest_class_share": round(v[3] / max(v[2], 1), 3),
+                                            "surface_lanes_per_iter": round(v[2] / max(v[0], 1), 1),
+                                            "iters_by_bsdf_classes": [round(x / max(sum(v[4:8]), 1), 3) for x in v[4:8]],
+                                            "shade_cycles_per_iter_by_bsdf_classes": [round(c / max(n, 1)) for n, c in zip(v[4:8], v[8:12])]})(d["divergence"]),
                   "per_sample": {k: round(d[k] / max(d["samples"], 1), 2) for k in ("closest_rays", "shadow_rays", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow", "bounces")}}))

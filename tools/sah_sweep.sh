@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box: SAH constants of the BVH builders against render throughput (env overrides are for sweeps only)
+# GPU box: SAH constants of the BVH builders against render throughput.  The overrides exist only in a -DMI355PT_TUNING build:
+#   tools/build_variant.sh tuning -DMI355PT_TUNING   (here), then   MI355PT_LIB=build_variants/libmi355pt_tuning.so tools/sah_sweep.sh
 cd "$(dirname "$0")/.."
 for scene in ${1:-3}; do
 for leaf in ${LEAFS:-2 3 4}; do

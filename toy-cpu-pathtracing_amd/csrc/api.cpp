@@ -496,6 +496,8 @@ static int render_accum_range(const mi355pt_scene* s, const mi355pt_camera* cam,
             stats->spectrum_evals = h.spectrum_evals; stats->textured_lookups = h.textured_lookups;
             for (int i = 0; i < 10; ++i) stats->phase_cycles[i] = h.phase_cycles[i];
             for (int i = 0; i < 8; ++i) stats->wave_steps[i] = h.wave_steps[i];
+            for (int i = 0; i < 16; ++i) stats->busy_hist[i] = h.busy_hist[i >> 3][i & 7];
+            for (int i = 0; i < 12; ++i) stats->divergence[i] = h.divergence[i];
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }

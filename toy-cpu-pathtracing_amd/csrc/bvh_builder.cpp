@@ -107,8 +107,10 @@ struct Builder {
 }  // namespace
 
 void bvh_build_config(float* cost_traverse, float* cost_tri, int* leaf_max) {
+#ifdef MI355PT_TUNING   // SAH sweeps (tools/sah_sweep.sh): not in the shipped library
     if (const char* e = getenv("MI355PT_BVH_COST_TRI")) COST_TRI = (float)atof(e);
     if (const char* e = getenv("MI355PT_BVH_LEAF")) LEAF_MAX = std::max(1, std::min(atoi(e), MAX_LEAF_TRIS));
+#endif
     *cost_traverse = COST_TRAVERSE; *cost_tri = COST_TRI; *leaf_max = LEAF_MAX;
 }
 

@@ -217,6 +217,8 @@ struct DevStats {
     unsigned long long closest_hits, bounces, spectrum_evals, textured_lookups;
     unsigned long long phase_cycles[10];
     unsigned long long wave_steps[8];
+    unsigned long long busy_hist[2][8];
+    unsigned long long divergence[12];
 };
 
 }  // namespace pt

@@ -343,6 +343,8 @@ struct StatCounters {
     uint32_t closest_rays, shadow_rays, nodes_closest, tris_closest, nodes_shadow, tris_shadow, closest_hits, bounces, spectrum_evals,
         textured_lookups, samples;
     uint32_t w[8];      // wave-level step counts (incremented by the first active lane only), mi355pt_stats.wave_steps
+    uint32_t hist[16];  // mi355pt_stats.busy_hist (wave leader only)
+    uint32_t dv[4];     // mi355pt_stats.divergence (lane 0 only)
 };
 PT_DEV bool wave_leader() { return __builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u; }
 
@@ -643,7 +645,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
     for (;;) {
         if (!done && cur >= 0) {
             if constexpr (WIDE) {
-                if (STATS) { st.nodes_shadow++; if (wave_leader()) st.w[2]++; }
+                if (STATS) { st.nodes_shadow++; const int busy = __popcll(__ballot(true)); if (wave_leader()) { st.w[2]++; st.hist[8 + ((busy - 1) >> 3)]++; } }
                 const Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_tmax);
                 // any-hit needs no order: continue into the first child hit, queue the others
                 int32_t nxt = 0; bool have = false;
@@ -661,7 +663,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
                 const float4* q = (const float4*)(sc.nodes + cur);
                 float4 nx = q[0], ny = q[1], nz = q[2];
                 int2 ch = *(const int2*)(q + 3);
-                if (STATS) { st.nodes_shadow++; if (wave_leader()) st.w[2]++; }
+                if (STATS) { st.nodes_shadow++; const int busy = __popcll(__ballot(true)); if (wave_leader()) { st.w[2]++; st.hist[8 + ((busy - 1) >> 3)]++; } }
                 float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
                 float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
                 float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;
@@ -792,7 +794,7 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
     for (;;) {
         if (!done && cur >= 0) {
             if constexpr (WIDE) {
-                if (STATS) { st.nodes_closest++; if (wave_leader()) st.w[0]++; }
+                if (STATS) { st.nodes_closest++; const int busy = __popcll(__ballot(true)); if (wave_leader()) { st.w[0]++; st.hist[0 + ((busy - 1) >> 3)]++; } }
                 Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_tbest);
                 sort4(h);
                 // nearest child next; the others go to the stack farthest first, so that the nearer of them is popped first
@@ -806,7 +808,7 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
                 const float4* q = (const float4*)(sc.nodes + cur);
                 float4 nx = q[0], ny = q[1], nz = q[2];
                 int2 ch = *(const int2*)(q + 3);
-                if (STATS) { st.nodes_closest++; if (wave_leader()) st.w[0]++; }
+                if (STATS) { st.nodes_closest++; const int busy = __popcll(__ballot(true)); if (wave_leader()) { st.w[0]++; st.hist[0 + ((busy - 1) >> 3)]++; } }
                 float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
                 float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
                 float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;

@@ -47,6 +47,8 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
     atomicAdd(&stats->spectrum_evals, (unsigned long long)st.spectrum_evals);
     atomicAdd(&stats->textured_lookups, (unsigned long long)st.textured_lookups);
     for (int i = 0; i < 8; ++i) if (st.w[i]) atomicAdd(&stats->wave_steps[i], (unsigned long long)st.w[i]);
+    for (int i = 0; i < 16; ++i) if (st.hist[i]) atomicAdd(&stats->busy_hist[i >> 3][i & 7], (unsigned long long)st.hist[i]);
+    for (int i = 0; i < 4; ++i) if (st.dv[i]) atomicAdd(&stats->divergence[i], (unsigned long long)st.dv[i]);
 }
 
 #ifndef PT_ANY_DEFERRED
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, dim_hash_tab, nullptr, 0u, 0u, nullptr, s_perm};
     StatCounters st{};
     unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dvc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // mi355pt_stats.divergence[4..11]
     unsigned long long t_loop0 = 0;
     if (STATS) t_loop0 = __builtin_amdgcn_s_memtime();
 
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         bool active = false;
         while (true) {
             unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
+            uint32_t bsdf_classes = 0u;
             if (STATS) ts0 = __builtin_amdgcn_s_memtime();
             const unsigned long long m_needy = __ballot(!active);
             if (m_needy != 0ull && pool_next < pool_size) {
@@ -171,7 +175,18 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
 #else
             if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st);
 #endif
-            if (STATS) ts2 = __builtin_amdgcn_s_memtime();
+            if (STATS) {
+                // material divergence of the shading stage (mi355pt_stats.divergence): classes among the lanes that shade a surface
+                const uint32_t mclass = (active && got) ? sc.materials[__float_as_uint(((const float4*)(sc.shade + hit.tri))[4].z)].type : 8u;
+                uint32_t classes = 0u, largest = 0u, lanes = 0u;
+                for (uint32_t c = 0u; c < 8u; ++c) {
+                    const uint32_t n = (uint32_t)__popcll(__ballot(mclass == c));
+                    classes += n ? 1u : 0u; largest = max(largest, n); lanes += n;
+                }
+                if (lane == 0 && lanes) { st.dv[0]++; st.dv[1] += classes; st.dv[2] += lanes; st.dv[3] += largest; }
+                bsdf_classes = classes - (__ballot(mclass == MT_EMISSIVE) != 0ull ? 1u : 0u);
+                ts2 = __builtin_amdgcn_s_memtime();
+            }
             bool end_path = false;
             ShadowReq sh{};
             if constexpr ((FEAT & FEAT_CC) != 0u) {
@@ -233,6 +248,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             }
             if (STATS) {
                 unsigned long long ts5 = __builtin_amdgcn_s_memtime();
+                dvc[min(bsdf_classes, 3u)] += 1ull; dvc[4 + min(bsdf_classes, 3u)] += ts3 - ts2;
                 tp[0] += ts1 - ts0; tp[1] += ts2 - ts1; tp[2] += ts3 - ts2; tp[3] += ts4 - ts3; tp[4] += ts5 - ts4;
                 if (tsa) { tp[6] += tsa - ts2; if (tsb) { tp[7] += tsb - tsa; tp[8] += ts3 - tsb; } else tp[7] += ts3 - tsa; } else tp[6] += ts3 - ts2;
             }
@@ -256,6 +272,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     if (STATS && lane == 0) {
         tp[5] = __builtin_amdgcn_s_memtime() - t_loop0;
         for (int i = 0; i < 10; ++i) atomicAdd(&stats->phase_cycles[i], tp[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&stats->divergence[4 + i], dvc[i]);
     }
     if (STATS) flush_stats(stats, st);
 }

@@ -83,12 +83,14 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "closest_rays", "shadow_rays", "nodes_closest", "tris_closest",
                                           "nodes_shadow", "tris_shadow", "closest_hits", "bounces", "spectrum_evals",
                                           "textured_lookups")] + [("phase_cycles", C.c_uint64 * 10), ("kernel_ms", C.c_double), ("launches", C.c_uint32),
-                                                ("wave_steps", C.c_uint64 * 8)]
+                                                ("wave_steps", C.c_uint64 * 8), ("busy_hist", C.c_uint64 * 16), ("divergence", C.c_uint64 * 12)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
         d["phase_cycles"] = list(self.phase_cycles)
         d["wave_steps"] = list(self.wave_steps)
+        d["busy_hist"] = [list(self.busy_hist)[:8], list(self.busy_hist)[8:]]
+        d["divergence"] = list(self.divergence)
         return d
 
 
