@@ -87,11 +87,17 @@ struct alignas(16) DevInstance {
 static_assert(sizeof(DevInstance) == 80, "instance record");
 
 enum : uint32_t { SPK_CONSTANT = 0, SPK_SIGMOID = 1, SPK_LUT = 2, SPK_TEXTURE = 3, SPK_ILLUM = 4 };   // ILLUM: pad[0] = scale bits, id = illuminant LUT
+struct DevTexture {
+    uint32_t offset;   // texel offset into the RGBA8 pool
+    uint32_t w, h, pad;
+};
+
 struct DevSpectrum {
     uint32_t kind;
     uint32_t id;       // LUT index or texture index
     float c[3];        // constant in c[0] or sigmoid coefficients
-    uint32_t pad[3];
+    uint32_t pad[3];   // SPK_ILLUM: pad[0] = the scale (float bits); SPK_TEXTURE: the texture's DevTexture {offset, w, h}, so that a lookup
+                       // does not wait for a descriptor fetch between the material record and the texels
 };
 static_assert(sizeof(DevSpectrum) == 32, "spectrum param");
 
@@ -109,8 +115,9 @@ struct alignas(16) DevMaterial {
     uint32_t metallic_tex, roughness_tex;   // FloatParameter::Texture ids (red channel), ~0 = use the constants above
     uint32_t cc_thickness_tex;
     uint32_t cc_albedo_lut;   // clearcoat: first entry of this material's 64-entry coat-albedo table in DevScene::cc_albedo
+    DevTexture normal_desc;   // textures[normal_tex], embedded for the same reason as DevSpectrum::pad
 };
-static_assert(sizeof(DevMaterial) == 160, "material record");
+static_assert(sizeof(DevMaterial) == 176, "material record");
 
 struct alignas(16) DevLightTri {
     float p0[3]; float p1x;
@@ -136,11 +143,6 @@ struct alignas(16) DevLight {
     float pad1;
 };
 static_assert(sizeof(DevLight) == 64, "light record");
-
-struct DevTexture {
-    uint32_t offset;   // texel offset into the RGBA8 pool
-    uint32_t w, h, pad;
-};
 
 // EnvironmentLight (primitive/impls/environment_light.rs): DevScene::envs[DevScene::n_envs], in light-list order
 struct DevEnv {

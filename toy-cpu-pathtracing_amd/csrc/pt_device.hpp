@@ -279,12 +279,26 @@ PT_DEV float sigmoid_value(float c0, float c1, float c2, float lambda) {   // rg
 struct U8UnitTable { float v[256]; };
 constexpr U8UnitTable make_u8_unit() { U8UnitTable t{}; for (int i = 0; i < 256; ++i) t.v[i] = (float)i / 255.0f; return t; }
 __device__ constexpr U8UnitTable U8_UNIT = make_u8_unit();
+#ifndef PT_U8_VALU
+#define PT_U8_VALU 1
+#endif
+// (float)c / 255.0f in four VALU instructions and no memory round trip: q = c * fl(1/255) is off by an ulp for 126 of the 256 values; one
+// residual step q + (c - 255 q) * fl(1/255), both in fma, is the correctly rounded quotient for every c in 0..255 (checked exhaustively on
+// the host with glibc's fmaf, tests/test_abi.py).  The table variant put a dependent gather between the texel fetch and the colour maths.
+PT_DEV float u8_unit(uint32_t c) {
+#if PT_U8_VALU
+    const float x = (float)c, r = 1.0f / 255.0f;
+    const float q = x * r;
+    return fmaf(fmaf(-255.0f, q, x), r, q);
+#else
+    return U8_UNIT.v[c];
+#endif
+}
 PT_DEV void fetch_texel(const DevScene& sc, const DevTexture& t, uint32_t x, uint32_t y, float out[3]) {
     uint32_t v = sc.texels[t.offset + y * t.w + x];
-    out[0] = U8_UNIT.v[v & 255u]; out[1] = U8_UNIT.v[(v >> 8) & 255u]; out[2] = U8_UNIT.v[(v >> 16) & 255u];   // = (float)c / 255.0f, exactly
+    out[0] = u8_unit(v & 255u); out[1] = u8_unit((v >> 8) & 255u); out[2] = u8_unit((v >> 16) & 255u);   // = (float)c / 255.0f, exactly
 }
-PT_DEV void bilinear_rgb(const DevScene& sc, uint32_t tex, f2 uv, float out[3]) {   // texture/sampler.rs:6-45
-    DevTexture t = sc.textures[tex];
+PT_DEV void bilinear_rgb(const DevScene& sc, const DevTexture& t, f2 uv, float out[3]) {   // texture/sampler.rs:6-45
     float u = fabsf(uv.x - truncf(uv.x));
     float v = 1.0f - fabsf(uv.y - truncf(uv.y));
     float x = u * ((float)t.w - 1.0f), y = v * ((float)t.h - 1.0f);
@@ -301,6 +315,19 @@ PT_DEV void bilinear_rgb(const DevScene& sc, uint32_t tex, f2 uv, float out[3]) 
         out[c] = top * (1.0f - fy) + bottom * fy;
     }
 }
+PT_DEV void bilinear_rgb(const DevScene& sc, uint32_t tex, f2 uv, float out[3]) { const DevTexture t = sc.textures[tex]; bilinear_rgb(sc, t, uv, out); }
+// The 64 z nodes of the table (256 B) live in LDS: the search for the z cell is a chain of 6 dependent reads, then 2 more for the cell's
+// ends — LDS round trips (~100 cycles) instead of L1 ones (several hundred under this kernel's load) on the critical path of every
+// textured lookup.  Filled by the kernel's prologue (pt_kernel.hpp); the LDS allocation stays inside the same 512-B granule.
+#ifndef PT_ZNODES_LDS
+#define PT_ZNODES_LDS 1
+#endif
+#if PT_ZNODES_LDS
+static __shared__ float s_znodes[64];
+#define PT_ZNODE(sc, i) s_znodes[i]
+#else
+#define PT_ZNODE(sc, i) (sc).z_nodes[i]
+#endif
 // RgbToSpectrumTable::get for gamma-encoded sRGB input (rgb_sigmoid_polynomial.rs:87-155); table repacked to float4 cells.
 PT_DEV void rgb2spec_lookup(const DevScene& sc, const float enc[3], float c[3]) {
     float rgb[3];
@@ -316,13 +343,26 @@ PT_DEV void rgb2spec_lookup(const DevScene& sc, const float enc[3], float c[3]) 
     float x = r1 * 63.0f / z, y = r2 * 63.0f / z;
     int xi = min((int)x, 62), yi = min((int)y, 62);
     // first i in [0,62] with z_nodes[i+1] > z (else 62): the nodes increase monotonically -> binary search
+#if PT_ZNODES_LDS
+    // = the number of nodes 1..63 that are not above z, at most 62 (the nodes increase monotonically; a NaN z counts them all, like the
+    // reference's search that finds no node above it): two rounds of independent LDS reads — every eighth node, then the seven inside
+    // the octant — instead of a chain of six dependent ones
+    int c1 = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) c1 += !(s_znodes[8 * k] > z) ? 1 : 0;
+    int zi = 8 * c1;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) zi += !(s_znodes[8 * c1 + j] > z) ? 1 : 0;
+    zi = min(zi, 62);
+#else
     int lo = 0, hi = 62;
-    if (!(sc.z_nodes[63] > z)) lo = 62;
+    if (!(PT_ZNODE(sc, 63) > z)) lo = 62;
     else {
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (sc.z_nodes[mid + 1] > z) hi = mid; else lo = mid + 1; }
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (PT_ZNODE(sc, mid + 1) > z) hi = mid; else lo = mid + 1; }
     }
     int zi = lo;
-    float zn0 = sc.z_nodes[zi], zn1 = sc.z_nodes[zi + 1];
+#endif
+    float zn0 = PT_ZNODE(sc, zi), zn1 = PT_ZNODE(sc, zi + 1);
     float dx = x - (float)xi, dy = y - (float)yi, dz = (z - zn0) / (zn1 - zn0);
     const float4* tab = (const float4*)sc.rgb2spec;
     size_t base = (((size_t)mc * 64 + zi) * 64 + yi) * 64 + xi;
@@ -357,7 +397,7 @@ PT_DEV void eval_spectrum(const DevScene& sc, const DevSpectrum& sp, const Wl& w
     if (TEX && kind == SPK_TEXTURE) {
         if (STATS) st.textured_lookups++;
         float rgb[3], c[3];
-        bilinear_rgb(sc, sp.id, uv, rgb);
+        bilinear_rgb(sc, DevTexture{sp.pad[0], sp.pad[1], sp.pad[2], 0u}, uv, rgb);
         rgb2spec_lookup(sc, rgb, c);
         c0 = c[0]; c1 = c[1]; c2 = c[2];
         kind = SPK_SIGMOID;

@@ -100,6 +100,9 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     uint32_t* stack = s_stack + lane;
     // murmur(dimension, seed) comes straight from its 1 KB global table (L1-resident): the LDS it used holds the tile's film
     for (uint32_t k = lane; k < 96u; k += 64u) s_perm[k] = (uint8_t)((perm_packed(k >> 2) >> (2u * (k & 3u))) & 3u);
+#if PT_ZNODES_LDS
+    if constexpr ((FEAT & (FEAT_TEX | FEAT_EMTEX | FEAT_ENV)) != 0u) s_znodes[lane] = sc.z_nodes[lane];   // rgb2spec_lookup's z search (pt_device.hpp)
+#endif
     __syncthreads();
     SamplerCtx sctx{prm.sampler, prm.seed, prm.log2_spp, prm.n_base4_digits, cam.width, dim_hash_tab, nullptr, 0u, 0u, nullptr, s_perm};
     StatCounters st{};

@@ -79,7 +79,7 @@ PT_DEV DevSpectrum load_spectrum(const DevSpectrum* p) {
     float4 a = q[0], b = q[1];
     DevSpectrum s;
     s.kind = __float_as_uint(a.x); s.id = __float_as_uint(a.y); s.c[0] = a.z; s.c[1] = a.w; s.c[2] = b.x;
-    s.pad[0] = __float_as_uint(b.y);
+    s.pad[0] = __float_as_uint(b.y); s.pad[1] = __float_as_uint(b.z); s.pad[2] = __float_as_uint(b.w);
     return s;
 }
 
@@ -431,7 +431,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             Frame nf;
             if ((FEAT & FEAT_TEX) && mat->normal_tex != 0xffffffffu) {
                 float rgb[3];
-                bilinear_rgb(sc, mat->normal_tex, sf.uv, rgb);                // normal_texture.rs:39-66
+                bilinear_rgb(sc, mat->normal_desc, sf.uv, rgb);               // normal_texture.rs:39-66
                 float nx = rgb[0] * 2.0f - 1.0f, ny = rgb[1] * 2.0f - 1.0f, nz = rgb[2] * 2.0f - 1.0f;
                 if (mat->normal_flip_y) ny = -ny;
                 float len = sqrtf(nx * nx + ny * ny + nz * nz);

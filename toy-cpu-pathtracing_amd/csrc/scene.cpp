@@ -464,6 +464,10 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         std::vector<float> cc_tab;
         std::vector<DevMaterial> mats = materials;
         for (DevMaterial& m : mats) {
+            // texture descriptors ride in the records that name the texture (layout.hpp)
+            m.normal_desc = m.normal_tex != 0xffffffffu ? dtex[m.normal_tex] : DevTexture{0, 0, 0, 0};
+            for (DevSpectrum* sp : {&m.color, &m.eta, &m.cc_tint})
+                if (sp->kind == SPK_TEXTURE) { sp->pad[0] = dtex[sp->id].offset; sp->pad[1] = dtex[sp->id].w; sp->pad[2] = dtex[sp->id].h; }
             m.cc_albedo_lut = 0;
             if (m.type != MT_CLEARCOAT) continue;
             float r = (m.cc_ior - 1.0f) / (m.cc_ior + 1.0f);
