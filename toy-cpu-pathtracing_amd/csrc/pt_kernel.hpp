@@ -60,16 +60,15 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 // MODE compiles the renderer strategy and the sampler in (MODE_GENERIC reads them from DevParams): the branches on
 // prm.strategy / the sampler mode fold away, worth +2.5 % on C2 (MIS + Sobol), +1.3 % on C5 (NEE + Sobol).
 enum : uint32_t { MODE_GENERIC = 0, MODE_MIS_SOBOL = 1, MODE_NEE_SOBOL = 2 };
-// Which tree the cooperative traversals walk (both are on the device).  The 4-wide tree halves the dependent node round trips per ray
-// (18 -> ~10 wave steps per closest-hit trace) and is worth +3...4.5 % — except in the kernel specialised for textured Lambert scenes
-// (FEAT_TEX alone: C2's kernel), where the wider node step's registers push the shading phase from 108 to 132 B of scratch per lane and
-// the same tree costs 4 % (same-box A/B: scene 3 1 467 vs 1 526, scenes 4 / 5 alike; scene 0 — the SAME geometry without textures —
-// 1 791 vs 1 721, scene 8 1 498 vs 1 434, scene 10 1 491 vs 1 429, scene 17 1 056 vs 1 025).  Measured per kernel, like every
-// register-budget decision here.
-#ifndef PT_WIDE_ALL
-#define PT_WIDE_ALL 0
+// Which tree the cooperative traversals walk (both are on the device; the plain traversals of the probes and of the canonical-count
+// mode walk the BVH2).  The 4-wide tree halves the dependent node round trips per ray (18 -> ~10 wave steps per closest-hit trace): +3...4.5 %
+// on every kernel, and +4.7 % on the kernel specialised for textured Lambert scenes (C2's) once that kernel stopped spilling around the wider
+// step (round 2: machine LICM off, see the Makefile; before that the same tree cost it 4 % and it kept the BVH2).  PT_WIDE_BVH=0 builds the
+// BVH2 form for A/B runs.
+#ifndef PT_WIDE_BVH
+#define PT_WIDE_BVH 1
 #endif
-template <uint32_t FEAT> constexpr bool wide_bvh() { return PT_WIDE_ALL || FEAT != FEAT_TEX; }
+template <uint32_t FEAT> constexpr bool wide_bvh() { return PT_WIDE_BVH != 0; }
 template <bool STATS, uint32_t FEAT, uint32_t MODE = MODE_GENERIC>
 __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WAVES)) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm_in, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, float* __restrict__ partial, unsigned* __restrict__ work_counter,
