@@ -936,4 +936,187 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
     return found;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ONE cooperative traversal for both rays a path vertex spawns: the light connection's any-hit ray and the next closest-hit ray.
+// They are independent (the connection only decides whether a contribution already computed is added), so the wave walks them as one
+// pool of up to 128 rays.  A wave's step count is bounded below by the depth of the deepest path it follows, not by the number of rays
+// (stealing spreads breadth, not depth): traced one after the other the two cost ~18 + ~14 node steps per iteration, together ~20.
+// Mechanics are those of trace_closest_coop / trace_any_deferred — lanes only walk nodes, queue (triangle, ray) pairs in the LDS ring, the
+// wave tests the ring densely, idle lanes steal — plus: a ray id is (owner lane | kind << 6); a lane that has both rays walks its closest-hit
+// ray first and keeps the shadow ray PENDING, to start it when it runs dry — or to hand it whole to an idle lane in a steal round, which is
+// the largest subtree there is.  Results: closest hits merge through atomicMin on (t bits << 32 | triangle), occlusion is one bit per owner.
+struct PairLds { uint32_t* ring; unsigned long long* best; uint32_t* occl; uint32_t* pair; };   // ring[ANY_RING], best[64], occl[2], pair[64]
+constexpr uint32_t RAY_ANY = 64u;             // kind bit of a ray id
+
+template <bool STATS, bool WIDE>
+PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f3 s_ro, f3 s_rd, float s_tmax, bool s_want, uint32_t* stack,
+                            uint32_t lane, const PairLds& L, Hit& hit, bool& c_found, bool& s_occluded, StatCounters& st) {
+    if (!c_want) { c_rd = mk3(0.0f, 0.0f, 1.0f); c_ro = mk3(0.0f, 0.0f, 0.0f); }
+    if (!s_want) { s_rd = mk3(0.0f, 0.0f, 1.0f); s_ro = mk3(0.0f, 0.0f, 0.0f); s_tmax = 0.0f; }
+    const RaySetup crs = setup_ray(c_rd), srs = setup_ray(s_rd);
+    const uint32_t c_kpack = (uint32_t)crs.kx | ((uint32_t)crs.ky << 2) | ((uint32_t)crs.kz << 4);
+    const uint32_t s_kpack = (uint32_t)srs.kx | ((uint32_t)srs.ky << 2) | ((uint32_t)srs.kz << 4);
+    L.best[lane] = (0x7f7fffffull << 32) | 0xffffffffull;                 // (FLT_MAX, no triangle)
+    if (lane < 2) L.occl[lane] = 0u;
+    __syncthreads();
+    const int32_t root = WIDE ? sc.root4 : sc.root;
+    // the ray this lane is WALKING (box tests see distances <= 1e30, see trace_any_deferred); `pend`: its own shadow ray is still to be started
+    f3 w_ro = c_want ? c_ro : s_ro, w_inv = c_want ? crs.inv : srs.inv;
+    float w_t = c_want ? 1e30f : fminf(s_tmax, 1e30f);
+    uint32_t ow = c_want ? lane : (lane | RAY_ANY);
+    bool pend = c_want && s_want;
+    bool done = !c_want && !s_want;
+    int sp = 0, sb = 0;
+    int32_t cur = root;
+    uint32_t leaf_off = 0;
+    uint32_t head = 0, tail = 0;
+    if (STATS) { if (c_want) st.closest_rays++; if (s_want) st.shadow_rays++; }
+
+    auto flush = [&](uint32_t n) {            // test ring entries [head, head + n), n <= 64
+        const bool valid = lane < n;
+        const uint32_t e = valid ? L.ring[(head + lane) & (ANY_RING - 1u)] : (lane << 25);
+        const uint32_t id = e >> 25, own = id & 63u, tri = e & 0x01ffffffu;
+        const bool any = (id & RAY_ANY) != 0u;
+        // the owner's ray of the entry's kind: both kinds are shuffled (a lane cannot know which of its two rays the asker wants)
+        const f3 co = mk3(__shfl(c_ro.x, own), __shfl(c_ro.y, own), __shfl(c_ro.z, own)), so = mk3(__shfl(s_ro.x, own), __shfl(s_ro.y, own), __shfl(s_ro.z, own));
+        const f3 cd = mk3(__shfl(c_rd.x, own), __shfl(c_rd.y, own), __shfl(c_rd.z, own)), sd = mk3(__shfl(s_rd.x, own), __shfl(s_rd.y, own), __shfl(s_rd.z, own));
+        const uint32_t ck = __shfl(c_kpack, own), sk = __shfl(s_kpack, own);
+        const float csx = __shfl(crs.sx, own), csy = __shfl(crs.sy, own), csz = __shfl(crs.sz, own);
+        const float ssx = __shfl(srs.sx, own), ssy = __shfl(srs.sy, own), ssz = __shfl(srs.sz, own);
+        const float stm = __shfl(s_tmax, own);
+        if (valid) {
+            const f3 o2 = any ? so : co, d2 = any ? sd : cd;
+            const uint32_t kp = any ? sk : ck;
+            const float sx = any ? ssx : csx, sy = any ? ssy : csy, sz = any ? ssz : csz;
+            const float t_lim = any ? stm : __uint_as_float((uint32_t)(L.best[own] >> 32));
+            TriVerts tv = load_tri(sc.tris, tri);
+            float t, b0, b1, b2;
+            if (STATS) { if (any) { st.tris_shadow++; } else { st.tris_closest++; } if (wave_leader()) st.w[1]++; }
+            if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, t_lim, tv, t, b0, b1, b2)) {
+                if (any) atomicOr(&L.occl[own >> 5], 1u << (own & 31u));
+                else atomicMin(&L.best[own], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)tri);
+            }
+        }
+        head += n;
+        __syncthreads();
+        // feedback for the ray this lane walks: a shadow ray that is occluded is finished, a closest-hit ray prunes with the best distance so far
+        const uint32_t wl_ = ow & 63u;
+        if (ow & RAY_ANY) { if ((L.occl[wl_ >> 5] >> (wl_ & 31u)) & 1u) done = true; }
+        else w_t = fminf(w_t, __uint_as_float((uint32_t)(L.best[wl_] >> 32)));
+    };
+
+    for (;;) {
+        if (!done && cur >= 0) {
+            if (STATS) { if (ow & RAY_ANY) st.nodes_shadow++; else st.nodes_closest++; if (wave_leader()) st.w[0]++; }
+            if constexpr (WIDE) {
+                Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_t);
+                sort4(h);                 // nearest first (any-hit does not need the order, and does not mind it)
+                if (h.n[3] < INFINITY) { stack[sp * 64] = (uint32_t)h.link[3]; ++sp; }
+                if (h.n[2] < INFINITY) { stack[sp * 64] = (uint32_t)h.link[2]; ++sp; }
+                if (h.n[1] < INFINITY) { stack[sp * 64] = (uint32_t)h.link[1]; ++sp; }
+                if (h.n[0] < INFINITY) cur = h.link[0];
+                else if (sp == sb) done = true;
+                else { --sp; cur = (int32_t)stack[sp * 64]; }
+            } else {
+                const float4* q = (const float4*)(sc.nodes + cur);
+                float4 nx = q[0], ny = q[1], nz = q[2];
+                int2 ch = *(const int2*)(q + 3);
+                float l0x = (nx.x - w_ro.x) * w_inv.x, h0x = (nx.z - w_ro.x) * w_inv.x;
+                float l1x = (nx.y - w_ro.x) * w_inv.x, h1x = (nx.w - w_ro.x) * w_inv.x;
+                float l0y = (ny.x - w_ro.y) * w_inv.y, h0y = (ny.z - w_ro.y) * w_inv.y;
+                float l1y = (ny.y - w_ro.y) * w_inv.y, h1y = (ny.w - w_ro.y) * w_inv.y;
+                float l0z = (nz.x - w_ro.z) * w_inv.z, h0z = (nz.z - w_ro.z) * w_inv.z;
+                float l1z = (nz.y - w_ro.z) * w_inv.z, h1z = (nz.w - w_ro.z) * w_inv.z;
+                float n0 = fmaxf(fmaxf(fminf(l0x, h0x), fminf(l0y, h0y)), fmaxf(fminf(l0z, h0z), 0.0f));
+                float f0 = fminf(fminf(fmaxf(l0x, h0x), fmaxf(l0y, h0y)), fminf(fmaxf(l0z, h0z), w_t));
+                float n1 = fmaxf(fmaxf(fminf(l1x, h1x), fminf(l1y, h1y)), fmaxf(fminf(l1z, h1z), 0.0f));
+                float f1 = fminf(fminf(fmaxf(l1x, h1x), fmaxf(l1y, h1y)), fminf(fmaxf(l1z, h1z), w_t));
+                bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+                if (hit0 && hit1) {
+                    bool first0 = n0 <= n1;
+                    stack[sp * 64] = (uint32_t)(first0 ? ch.y : ch.x); ++sp;
+                    cur = first0 ? ch.x : ch.y;
+                } else if (hit0) cur = ch.x;
+                else if (hit1) cur = ch.y;
+                else if (sp == sb) done = true;
+                else { --sp; cur = (int32_t)stack[sp * 64]; }
+            }
+        }
+        // lanes sitting in a leaf queue up to two of its triangles per step, then move on
+        const bool at_leaf = !done && cur < 0;
+        const unsigned long long m1 = __ballot(at_leaf);
+        if (m1 != 0ull) {
+            uint32_t first = 0, rem = 0;
+            if (at_leaf) { first = leaf_first(cur) + leaf_off; rem = leaf_count(cur) - leaf_off; }
+            const uint32_t a = rem < 2u ? rem : 2u;
+            const unsigned long long m2 = __ballot(a == 2u);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t pos = tail + (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
+            if (a >= 1u) L.ring[pos & (ANY_RING - 1u)] = first | (ow << 25);
+            if (a == 2u) L.ring[(pos + 1u) & (ANY_RING - 1u)] = (first + 1u) | (ow << 25);
+            tail += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+            if (at_leaf) {
+                if (rem > 2u) leaf_off += 2u;
+                else { leaf_off = 0u; if (sp == sb) done = true; else { --sp; cur = (int32_t)stack[sp * 64]; } }
+            }
+            __syncthreads();
+            while (tail - head >= 64u) flush(64u);
+        }
+        // a lane that ran dry starts its own pending shadow ray
+        if (done && pend) {
+            pend = false; done = false;
+            w_ro = s_ro; w_inv = srs.inv; w_t = fminf(s_tmax, 1e30f); ow = lane | RAY_ANY;
+            cur = root; sp = sb = 0; leaf_off = 0u;
+        }
+        const unsigned long long m_act = __ballot(!done);
+        if (m_act == 0ull) break;
+        // work stealing: idle lanes take, from lanes that still have something to give, either the PENDING shadow ray as a whole or the
+        // bottom stack entry (the largest pending subtree) together with the working ray it belongs to
+        if (__popcll(m_act) <= PT_STEAL_MAX_ACTIVE) {
+            const bool donor = !done && (pend || sp > sb);
+            const unsigned long long m_donor = __ballot(donor);
+            if (m_donor != 0ull) {
+                const unsigned long long m_idle = ~m_act;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t n_pairs = min((uint32_t)__popcll(m_donor), (uint32_t)__popcll(m_idle));
+                const uint32_t rank = (uint32_t)__popcll((donor ? m_donor : m_idle) & below);
+                if (donor && rank < n_pairs) L.pair[rank] = lane;
+                __syncthreads();
+                const bool taker = done && rank < n_pairs;
+                const uint32_t from = taker ? L.pair[rank] : lane;
+                // what this lane would give: its pending shadow ray from the root, else the bottom of its stack with its working ray
+                const bool give_ray = pend;
+                const f3 g_ro = give_ray ? s_ro : w_ro, g_inv = give_ray ? srs.inv : w_inv;
+                const float g_t = give_ray ? fminf(s_tmax, 1e30f) : w_t;
+                const uint32_t g_ow = give_ray ? (lane | RAY_ANY) : ow;
+                const int g_sb = give_ray ? -1 : sb;
+                const int d_sb = __shfl(g_sb, from);
+                const float rx = __shfl(g_ro.x, from), ry = __shfl(g_ro.y, from), rz = __shfl(g_ro.z, from);
+                const float ix = __shfl(g_inv.x, from), iy = __shfl(g_inv.y, from), iz = __shfl(g_inv.z, from);
+                const float tb = __shfl(g_t, from);
+                const uint32_t gow = __shfl(g_ow, from);
+                if (taker) {
+                    cur = d_sb < 0 ? root : (int32_t)(stack - lane)[d_sb * 64 + from];
+                    w_ro = mk3(rx, ry, rz); w_inv = mk3(ix, iy, iz); w_t = tb; ow = gow;
+                    sp = sb = 0; leaf_off = 0u; done = false;
+                }
+                if (donor && rank < n_pairs) { if (give_ray) pend = false; else ++sb; }
+                __syncthreads();
+            }
+        }
+    }
+    if (tail != head) flush(tail - head);     // stragglers' last pairs (tail - head < 64 here)
+    s_occluded = s_want && (((L.occl[lane >> 5] >> (lane & 31u)) & 1u) != 0u);
+    const unsigned long long key = L.best[lane];
+    const uint32_t tri = (uint32_t)key;
+    c_found = c_want && tri != 0xffffffffu;
+    if (c_found) {                                                           // the winner's barycentrics: same function, same inputs
+        TriVerts tv = load_tri(sc.tris, tri);
+        float t, b0, b1, b2;
+        intersect_triangle(c_ro, c_rd, crs.kx, crs.ky, crs.kz, crs.sx, crs.sy, crs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
+        hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = tri;
+        if (STATS) st.closest_hits++;
+    }
+}
+
 }  // namespace pt

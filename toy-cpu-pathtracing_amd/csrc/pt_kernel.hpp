@@ -54,6 +54,15 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 #ifndef PT_ANY_DEFERRED
 #define PT_ANY_DEFERRED 1
 #endif
+// ONE cooperative traversal per iteration for the next closest-hit rays AND the light connections of the vertex just shaded (trace_pair_coop,
+// pt_device.hpp): a wave's step count is bounded by its deepest ray, not by the ray count, so the two traversals together cost ~20 node
+// steps instead of ~18 + ~14.  The pending connection (11 registers) then lives across the shading stage: worth +2.4...+5 % where the kernel
+// has the registers (scene 3 1 716 -> 1 757, scene 0 1 814 -> 1 906, scene 8 1 525 -> 1 574, scene 10 1 519 -> 1 583), -7 % in the clearcoat
+// kernels (scene 17 NEE 1 180 -> 1 097: scratch 88 -> 196 B per lane at 3 waves per SIMD), which keep the two traversals.  Measured per kernel.
+#ifndef PT_MERGED_TRAVERSAL
+#define PT_MERGED_TRAVERSAL 1      // 0: never, 1: every kernel without FEAT_CC, 2: every kernel
+#endif
+template <uint32_t FEAT> constexpr bool merged_traversal() { return PT_MERGED_TRAVERSAL == 2 || (PT_MERGED_TRAVERSAL == 1 && (FEAT & FEAT_CC) == 0u); }
 #ifndef PT_CLOSEST_COOP
 #define PT_CLOSEST_COOP 1      // needs PT_ANY_DEFERRED (shares its LDS ring)
 #endif
@@ -90,6 +99,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
 #if PT_CLOSEST_COOP
     __shared__ unsigned long long s_best[64];
     const ClosestLds closest_lds{s_ring, s_best, s_pair};
+    const PairLds pair_lds{s_ring, s_best, s_occl, s_pair};
 #endif
 #endif
     DevParams prm = prm_in;
@@ -151,6 +161,8 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         uint32_t my_pix = lane;
         Path P{};
         bool active = false;
+        constexpr bool MERGED = merged_traversal<FEAT>();
+        ShadowReq sh{};                                            // merged form: the light connection of the vertex just shaded, traced together with the NEXT closest-hit ray
         while (true) {
             unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
             uint32_t bsdf_classes = 0u;
@@ -171,12 +183,20 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             if (STATS) { ts1 = __builtin_amdgcn_s_memtime(); if (lane == 0) st.w[4]++; if (active) st.w[5]++; }
             Hit hit{};
             bool got = false;
-#if PT_CLOSEST_COOP
-            if (STATS && prm.stats_mode == 1u) { if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st); }
+            const bool canonical = STATS && prm.stats_mode == 1u;                    // plain per-lane traversals in the reference's order (step counts)
+            if (canonical) { if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st); }
+            else if constexpr (MERGED) {
+                // ONE traversal for this iteration's closest-hit rays and the light connections the previous shading left pending
+                bool occluded = false;
+                if (STATS && sh.on) st.w[6]++;
+                trace_pair_coop<STATS, wide_bvh<FEAT>()>(sc, P.ro, P.rd, active, sh.o, sh.d, sh.t, sh.on, stack, lane, pair_lds, hit, got, occluded, st);
+                if (sh.on && !occluded) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
+                }
+                sh.on = false;
+            }
             else got = trace_closest_coop<STATS, wide_bvh<FEAT>()>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st);
-#else
-            if (active) got = trace_closest<STATS>(sc, P.ro, P.rd, 3.402823466e+38f, stack, hit, st);
-#endif
             if (STATS) {
                 // material divergence of the shading stage (mi355pt_stats.divergence): classes among the lanes that shade a surface
                 const uint32_t mclass = (active && got) ? sc.materials[__float_as_uint(((const float4*)(sc.shade + hit.tri))[4].z)].type : 8u;
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 ts2 = __builtin_amdgcn_s_memtime();
             }
             bool end_path = false;
-            ShadowReq sh{};
+            if constexpr (!MERGED) sh = ShadowReq{};
             if constexpr ((FEAT & FEAT_CC) != 0u) {
                 ShadeCtx C;
                 C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
@@ -212,28 +232,24 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             }
             // a light connection whose contribution is exactly zero (light behind the surface, f == 0) cannot change L whatever the
             // visibility test says: the production path does not trace it (the canonical-count mode does, like the reference)
-            if (!(STATS && prm.stats_mode == 1u) && sh.on && sh.c[0] == 0.0f && sh.c[1] == 0.0f && sh.c[2] == 0.0f && sh.c[3] == 0.0f) sh.on = false;
-#if PT_ANY_DEFERRED
-            if (__any(sh.on)) {
-                if (STATS && sh.on) st.w[6]++;
-                bool occluded = false;
-                if (STATS && prm.stats_mode == 1u) { if (sh.on) occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st); }
-                else occluded = trace_any_deferred<STATS, wide_bvh<FEAT>()>(sc, sh.o, sh.d, sh.t, sh.on, stack, lane, any_lds, st);
-                if (sh.on && !occluded) {
+            if (!canonical && sh.on && sh.c[0] == 0.0f && sh.c[1] == 0.0f && sh.c[2] == 0.0f && sh.c[3] == 0.0f) sh.on = false;
+            if (!active) sh.on = false;
+            {
+                // merged form: the connection of a CONTINUING path waits for the next iteration's traversal; a path that ends here with a
+                // connection pending (a failed BSDF sample after the light was sampled: rare) — and everything in the canonical-count mode — is traced now
+                const bool now = sh.on && (!MERGED || canonical || end_path);
+                if (__any(now)) {
+                    if (STATS && now) st.w[6]++;
+                    bool occluded = false;
+                    if (canonical) { if (now) occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st); }
+                    else occluded = trace_any_deferred<STATS, wide_bvh<FEAT>()>(sc, sh.o, sh.d, sh.t, now, stack, lane, any_lds, st);
+                    if (now && !occluded) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
+                        for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
+                    }
+                    if (now) sh.on = false;
                 }
             }
-#else
-            if (sh.on) {
-                if (STATS) st.w[6]++;
-                bool occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st);
-                if (!occluded) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
-                }
-            }
-#endif
             if (STATS) ts4 = __builtin_amdgcn_s_memtime();
             if (active && end_path) {
                 if (pout.L != nullptr) {
