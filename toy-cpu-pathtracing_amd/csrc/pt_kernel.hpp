@@ -305,15 +305,24 @@ struct PtLaunchArgs {
     DevScene sc; DevCamera cam; DevParams prm; const uint64_t* d_hash; float* d_accum; float* d_partial; unsigned* d_counter; DevStats* d_stats;
     int grid; hipStream_t stream; PathOut pout;
 };
-#define PT_FOR_EACH_FEATURE_SET(X) \
-    X(0u) X(FEAT_TEX) X(FEAT_DIEL) X(FEAT_METAL) X(FEAT_DIEL | FEAT_ROUGH) X(FEAT_DELTA | FEAT_MLIGHT) X(FEAT_CC) X(FEAT_CC | FEAT_TEX) X(FEAT_STD & ~FEAT_CC) X(FEAT_STD) X(FEAT_ALL)
+// The feature sets in two classes, compiled in separate translation units with their own backend options (Makefile): the sets without the
+// clearcoat code run at 4 waves per SIMD and gain from sinking / the AMDGPU pressure trackers, the clearcoat sets (3 waves per SIMD) lose.
+#define PT_FOR_EACH_PLAIN_SET(X) X(0u) X(FEAT_TEX) X(FEAT_DIEL) X(FEAT_METAL) X(FEAT_DIEL | FEAT_ROUGH) X(FEAT_DELTA | FEAT_MLIGHT) X(FEAT_STD & ~FEAT_CC)
+#define PT_FOR_EACH_CC_SET(X) X(FEAT_CC) X(FEAT_CC | FEAT_TEX) X(FEAT_STD) X(FEAT_ALL)
+#define PT_FOR_EACH_FEATURE_SET(X) PT_FOR_EACH_PLAIN_SET(X) PT_FOR_EACH_CC_SET(X)
+#define PT_CASE(F) case (F): hipLaunchKernelGGL((pt_kernel<false, (F), MODE>), dim3(a.grid), dim3(64), 0, a.stream, a.sc, a.cam, a.prm, a.d_hash, a.d_accum, a.d_partial, a.d_counter, a.d_stats, a.pout); break;
+template <uint32_t MODE>
+void launch_pt_plain(const PtLaunchArgs& a, uint32_t feat) {
+    switch (pick_features(feat)) { PT_FOR_EACH_PLAIN_SET(PT_CASE) default: break; }
+}
+template <uint32_t MODE>
+void launch_pt_cc(const PtLaunchArgs& a, uint32_t feat) {
+    switch (pick_features(feat)) { PT_FOR_EACH_CC_SET(PT_CASE) default: break; }
+}
+#undef PT_CASE
 template <uint32_t MODE>
 void launch_pt_mode(const PtLaunchArgs& a, uint32_t feat) {
-    switch (pick_features(feat)) {
-#define PT_CASE(F) case (F): hipLaunchKernelGGL((pt_kernel<false, (F), MODE>), dim3(a.grid), dim3(64), 0, a.stream, a.sc, a.cam, a.prm, a.d_hash, a.d_accum, a.d_partial, a.d_counter, a.d_stats, a.pout); break;
-        PT_FOR_EACH_FEATURE_SET(PT_CASE)
-#undef PT_CASE
-    }
+    if (pick_features(feat) & FEAT_CC) launch_pt_cc<MODE>(a, feat); else launch_pt_plain<MODE>(a, feat);
 }
 // resident waves per CU of the variant (launch bounds: 4 waves/SIMD, clearcoat variants 3): the persistent grid size
 template <uint32_t MODE>
@@ -327,7 +336,9 @@ int occupancy_pt_mode(uint32_t feat) {
     }
     return (e == hipSuccess && per_cu > 0) ? per_cu : 8;
 }
-void launch_pt_mis_sobol(const PtLaunchArgs& a, uint32_t feat);   // pt_kernels_mis.hip
-void launch_pt_nee_sobol(const PtLaunchArgs& a, uint32_t feat);   // pt_kernels_nee.hip
+void launch_pt_mis_sobol(const PtLaunchArgs& a, uint32_t feat);      // pt_kernels_mis.hip (plain sets; forwards the clearcoat sets)
+void launch_pt_mis_sobol_cc(const PtLaunchArgs& a, uint32_t feat);   // pt_kernels_mis_cc.hip
+void launch_pt_nee_sobol(const PtLaunchArgs& a, uint32_t feat);      // pt_kernels_nee.hip
+void launch_pt_nee_sobol_cc(const PtLaunchArgs& a, uint32_t feat);   // pt_kernels_nee_cc.hip
 
 }  // namespace pt
