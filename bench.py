@@ -268,7 +268,7 @@ def main():
 
 
 def scene_info(prod, scene):
-    return "flat single-level BVH2 (SAH; builder and timings follow), 64 B nodes with both child boxes, <=4 tris/leaf; " + prod.scene_info(scene)
+    return "flat single-level SAH BVH2 (64 B nodes with both child boxes, <=3 tris/leaf) collapsed to the 4-wide tree the kernels walk (128 B nodes); " + prod.scene_info(scene)
 
 
 if __name__ == "__main__":

@@ -29,9 +29,11 @@ struct Box {
 // SAH cost ratio and leaf size: defaults measured on MI355X; env overrides exist for sweeps only
 // With per-lane triangle tests a watertight test cost about two node steps and 2-triangle leaves were best; since leaves only
 // queue (triangle, ray) pairs that the whole wave tests densely, a triangle is cheaper than a node step: tools/sah_sweep.sh on
-// scenes 3 / 17 / 0 puts the plateau at 0.6-1.0 with leaves of up to 4 (+1.2 % over 2.0 / 2).
+// scenes 3 / 17 / 0 puts the plateau at 0.6-1.0 with leaves of up to 4 (+1.2 % over 2.0 / 2).  Re-swept with the 4-wide tree and the merged
+// traversal (round 2, scenes 3 / 8 / 15 / 17): leaves of up to 3 (1 844 / 1 608 / 977 / 1 185 Msamples/s against 1 823 / 1 591 / 977 / 1 184 with 4 and
+// 1 840 / 1 606 / 969 / 1 181 with 2; single-triangle leaves lose 10 %); forced median splits may still make leaves of MAX_LEAF_TRIS.
 static float COST_TRAVERSE = 1.0f, COST_TRI = 0.8f;
-static int LEAF_MAX = 4;
+static int LEAF_MAX = 3;
 
 struct Builder {
     const std::vector<BuildTri>& tris;
