@@ -56,19 +56,22 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 #endif
 // ONE cooperative traversal per iteration for the next closest-hit rays AND the light connections of the vertex just shaded (trace_pair_coop,
 // pt_device.hpp): a wave's step count is bounded by its deepest ray, not by the ray count, so the two traversals together cost ~20 node
-// steps instead of ~18 + ~14.  The pending connection (11 registers) then lives across the shading stage: worth +2.4...+5 % where the kernel
-// has the registers (scene 3 1 716 -> 1 757, scene 0 1 814 -> 1 906, scene 8 1 525 -> 1 574, scene 10 1 519 -> 1 583), -7 % in the clearcoat
-// kernels (scene 17 NEE 1 180 -> 1 097: scratch 88 -> 196 B per lane at 3 waves per SIMD), which keep the two traversals.  Measured per kernel.
+// steps instead of ~18 + ~14.  The price is the pending connection's 11 registers across one more stage.  Measured per kernel (same box):
+// kernels without the clearcoat code +2.4...+5 % (scene 3 1 716 -> 1 757, scene 0 1 814 -> 1 906, scene 8 1 525 -> 1 574, scene 10 1 519 -> 1 583);
+// clearcoat kernels (3 waves per SIMD) in the MIS specialisation +1.7 / +5.5 % (scenes 15 / 19), in the NEE specialisation -1.9 % (scene 17:
+// C5's kernel, scratch 88 -> 144 B per lane) — that one, and the generic-mode clearcoat kernels (not measured), keep the two traversals.
 #ifndef PT_MERGED_TRAVERSAL
-#define PT_MERGED_TRAVERSAL 1      // 0: never, 1: every kernel without FEAT_CC, 2: every kernel
+#define PT_MERGED_TRAVERSAL 1      // 0: never, 1: as measured (above), 2: every kernel
 #endif
-template <uint32_t FEAT> constexpr bool merged_traversal() { return PT_MERGED_TRAVERSAL == 2 || (PT_MERGED_TRAVERSAL == 1 && (FEAT & FEAT_CC) == 0u); }
+enum : uint32_t { MODE_GENERIC = 0, MODE_MIS_SOBOL = 1, MODE_NEE_SOBOL = 2 };
+template <uint32_t FEAT, uint32_t MODE> constexpr bool merged_traversal() {
+    return PT_MERGED_TRAVERSAL == 2 || (PT_MERGED_TRAVERSAL == 1 && ((FEAT & FEAT_CC) == 0u || MODE == MODE_MIS_SOBOL));
+}
 #ifndef PT_CLOSEST_COOP
 #define PT_CLOSEST_COOP 1      // needs PT_ANY_DEFERRED (shares its LDS ring)
 #endif
 // MODE compiles the renderer strategy and the sampler in (MODE_GENERIC reads them from DevParams): the branches on
 // prm.strategy / the sampler mode fold away, worth +2.5 % on C2 (MIS + Sobol), +1.3 % on C5 (NEE + Sobol).
-enum : uint32_t { MODE_GENERIC = 0, MODE_MIS_SOBOL = 1, MODE_NEE_SOBOL = 2 };
 // Which tree the cooperative traversals walk (both are on the device; the plain traversals of the probes and of the canonical-count
 // mode walk the BVH2).  The 4-wide tree halves the dependent node round trips per ray (18 -> ~10 wave steps per closest-hit trace): +3...4.5 %
 // on every kernel, and +4.7 % on the kernel specialised for textured Lambert scenes (C2's) once that kernel stopped spilling around the wider
@@ -90,6 +93,14 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     __shared__ uint32_t s_hi[SOBOL_HI_DIMS];
     __shared__ uint32_t s_p6[SOBOL_HI_DIMS];
     __shared__ unsigned s_work;
+#ifndef PT_PARK_LDS
+#define PT_PARK_LDS 1
+#endif
+    // The clearcoat kernels run 12 waves per CU, so each has 3.4 KB of LDS the 16-wave kernels do not: the record of the BSDF sample that
+    // spawned the ray in flight (f, pdf, the vertex left: 8 dwords per lane, read only at the start of the next vertex's shading) waits there
+    // during the traversals instead of in registers the allocator would spill to scratch
+    constexpr bool PARK = PT_PARK_LDS != 0 && (FEAT & FEAT_CC) != 0u;
+    __shared__ float s_park[PARK ? 8 * 64 : 1];
     __shared__ uint8_t s_perm[96];
 #if PT_ANY_DEFERRED
     __shared__ uint32_t s_ring[ANY_RING];
@@ -106,6 +117,21 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     if constexpr (MODE == MODE_MIS_SOBOL) { prm.strategy = 2u; prm.sampler = 1u; }
     if constexpr (MODE == MODE_NEE_SOBOL) { prm.strategy = 1u; prm.sampler = 1u; }
     const uint32_t lane = threadIdx.x;
+    auto park = [&](Path& Q) {
+        if constexpr (PARK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s_park[i * 64 + lane] = Q.pf[i]; Q.pf[i] = 0.0f; }
+            s_park[4 * 64 + lane] = Q.p_pdf; s_park[5 * 64 + lane] = Q.prev_pos.x; s_park[6 * 64 + lane] = Q.prev_pos.y; s_park[7 * 64 + lane] = Q.prev_pos.z;
+            Q.p_pdf = 0.0f; Q.prev_pos = mk3(0.0f, 0.0f, 0.0f);
+        }
+    };
+    auto unpark = [&](Path& Q) {
+        if constexpr (PARK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Q.pf[i] = s_park[i * 64 + lane];
+            Q.p_pdf = s_park[4 * 64 + lane]; Q.prev_pos = mk3(s_park[5 * 64 + lane], s_park[6 * 64 + lane], s_park[7 * 64 + lane]);
+        }
+    };
     uint32_t* stack = s_stack + lane;
     // murmur(dimension, seed) comes straight from its 1 KB global table (L1-resident): the LDS it used holds the tile's film
     for (uint32_t k = lane; k < 96u; k += 64u) s_perm[k] = (uint8_t)((perm_packed(k >> 2) >> (2u * (k & 3u))) & 3u);
@@ -160,8 +186,9 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         uint32_t pool_next = 0u;                                   // wave-uniform
         uint32_t my_pix = lane;
         Path P{};
+        park(P);
         bool active = false;
-        constexpr bool MERGED = merged_traversal<FEAT>();
+        constexpr bool MERGED = merged_traversal<FEAT, MODE>();
         ShadowReq sh{};                                            // merged form: the light connection of the vertex just shaded, traced together with the NEXT closest-hit ray
         while (true) {
             unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
 #pragma unroll
                     for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
                 }
-                sh.on = false;
+                sh = ShadowReq{};      // consumed: every field dead from here on, for every lane — none of them is carried through the shading stage (+2 % on scenes 0 / 8)
             }
             else got = trace_closest_coop<STATS, wide_bvh<FEAT>()>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st);
             if (STATS) {
@@ -211,6 +238,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             }
             bool end_path = false;
             if constexpr (!MERGED) sh = ShadowReq{};
+            unpark(P);
             if constexpr ((FEAT & FEAT_CC) != 0u) {
                 ShadeCtx C;
                 C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
@@ -223,6 +251,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             } else {
                 if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
             }
+            park(P);
             if (STATS) {
                 ts3 = __builtin_amdgcn_s_memtime();
                 // the stamps inside shade_vertex are taken by the lanes that reach them: make them wave-level (first lane that has one)
