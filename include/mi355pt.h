@@ -119,7 +119,8 @@ typedef struct mi355pt_params {
     uint32_t shard_index, shard_count; /* 0,1 (or 0,0) = whole frame */
     uint32_t collect_stats;            /* run the instrumented kernel variant and fill mi355pt_stats: 1 = with the reference's
                                         * traversal order (the canonical per-sample node/triangle counts of SURVEY.md 8d),
-                                        * 2 = with the production traversal (cooperative, slightly more nodes; lane-use diagnostics) */
+                                        * 2 = with the production traversal (cooperative, slightly more nodes; lane-use diagnostics; scenes without clearcoat / textured
+                                        * emitters run the instrumented kernel whose traversal has the production form of their kernels) */
     float rr_gate_slack;               /* diagnostic, 0 = the reference: apply_russian_roulette skips the roulette when
                                         * max(T) >= 1 (base_renderer.rs:76-92); with a slack s the gate is max(T) >= 1 - s.
                                         * Used by the parity tests to show that GPU / oracle path flips on solid constant-eta
@@ -146,7 +147,7 @@ typedef struct mi355pt_stats {
      * (summed over iterations), 6 lanes with a shadow ray, 7 spare */
     uint64_t wave_steps[8];
     /* diagnostic (collect_stats = 2): how many lanes of the wave were still walking when a node step was issued — wave-level node
-     * steps of the cooperative traversals by busy-lane count, bucket k = 8k+1 .. 8k+8 lanes; [0..7] closest-hit, [8..15] any-hit.  The
+     * steps of the cooperative traversals by busy-lane count, bucket k = 8k+1 .. 8k+8 lanes; [0..7] closest-hit, [8..15] any-hit (where one traversal walks both kinds of ray, its steps are in [0..7]).  The
      * low buckets are the tail a lock-step traversal pays for its deepest ray */
     uint64_t busy_hist[16];
     /* diagnostic (collect_stats = 2): material divergence of the shading stage, summed over wave iterations — 0 iterations with

@@ -411,7 +411,8 @@ static int render_accum_range(const mi355pt_scene* s, const mi355pt_camera* cam,
     uint32_t n_tiles_total = dp.tiles_x * dp.tiles_y;
     uint32_t n_tiles = n_tiles_total > dp.shard_index ? (n_tiles_total - dp.shard_index + dp.shard_count - 1) / dp.shard_count : 0;
     if (n_tiles == 0) return MI355PT_OK;
-    int waves = resident_waves((stats && p->collect_stats) ? (uint32_t)FEAT_ALL : s->impl.features);   // the instrumented variant is the all-features kernel
+    // (the instrumented variants: every feature but clearcoat / textured emitters when the scene has neither, else the all-features kernel)
+    int waves = resident_waves((stats && p->collect_stats) ? ((s->impl.features & (FEAT_CC | FEAT_EMTEX)) == 0u ? (uint32_t)(FEAT_STD & ~FEAT_CC) : (uint32_t)FEAT_ALL) : s->impl.features);
     // Work items.  A work item is a 2^b x 2^b pixel block of an 8x8 tile times a range of sample indices, its (pixel, sample)
     // pairs handed to the lanes as a pool.  Sobol: the fewer pixels an item has, the fewer Morton digits vary inside it, and only
     // varying digits (minus the two that have block-level tables) are hashed per draw (pt_device.hpp sampler_index): take the

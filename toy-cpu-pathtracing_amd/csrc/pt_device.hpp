@@ -1007,7 +1007,7 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
 
     for (;;) {
         if (!done && cur >= 0) {
-            if (STATS) { if (ow & RAY_ANY) st.nodes_shadow++; else st.nodes_closest++; if (wave_leader()) st.w[0]++; }
+            if (STATS) { if (ow & RAY_ANY) st.nodes_shadow++; else st.nodes_closest++; const int busy = __popcll(__ballot(true)); if (wave_leader()) { st.w[0]++; st.hist[(busy - 1) >> 3]++; } }   // (the pool's steps are booked as closest-hit steps)
             if constexpr (WIDE) {
                 Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_t);
                 sort4(h);                 // nearest first (any-hit does not need the order, and does not mind it)

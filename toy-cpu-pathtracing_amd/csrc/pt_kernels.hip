@@ -140,7 +140,12 @@ hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& 
                      unsigned* d_counter, DevStats* d_stats, bool stats, uint32_t feat, int grid, hipStream_t stream, const PathOut& pout) {
     const PtLaunchArgs a{sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, grid, stream, pout};
     if (stats) {
-        hipLaunchKernelGGL((pt_kernel<true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout);
+        // two instrumented variants: scenes without the clearcoat code get the one whose traversal has the production form (merged, 4 waves
+        // per SIMD), so that the lane-use diagnostics describe what the benchmarked kernels do
+        if ((feat & (FEAT_CC | FEAT_EMTEX)) == 0u)
+            hipLaunchKernelGGL((pt_kernel<true, FEAT_STD & ~FEAT_CC, MODE_GENERIC>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout);
+        else
+            hipLaunchKernelGGL((pt_kernel<true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout);
     } else if (prm.sampler == 1u && prm.strategy == 2u) launch_pt_mis_sobol(a, feat);
     else if (prm.sampler == 1u && prm.strategy == 1u) launch_pt_nee_sobol(a, feat);
     else launch_pt_mode<MODE_GENERIC>(a, feat);
