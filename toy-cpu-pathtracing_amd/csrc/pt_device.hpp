@@ -387,6 +387,8 @@ struct StatCounters {
     uint32_t dv[4];     // mi355pt_stats.divergence (lane 0 only)
 };
 PT_DEV bool wave_leader() { return __builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u; }
+// number of set bits of a wave mask below this lane (v_mbcnt: no lane-mask registers to keep, two instructions)
+PT_DEV uint32_t rank_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 // SpectrumParameter::sample(uv).sample(lambda)  (parameter.rs:38-47, spectrum.rs:32-46)
 template <bool STATS, bool TEX = true>
@@ -730,8 +732,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
             if (at_leaf) { first = leaf_first(cur) + leaf_off; rem = leaf_count(cur) - leaf_off; }
             const uint32_t a = rem < 2u ? rem : 2u;
             const unsigned long long m2 = __ballot(a == 2u);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const uint32_t pos = tail + (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
+            const uint32_t pos = tail + rank_below(m1) + rank_below(m2);
             if (a >= 1u) L.ring[pos & (ANY_RING - 1u)] = first | (owner << 26);
             if (a == 2u) L.ring[(pos + 1u) & (ANY_RING - 1u)] = (first + 1u) | (owner << 26);
             tail += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
@@ -753,10 +754,9 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
             if (m_donor != 0ull) {
                 since_steal = 0u;
                 const unsigned long long m_idle = ~m_act;
-                const unsigned long long below = (1ull << lane) - 1ull;
                 const uint32_t n_pairs = min((uint32_t)__popcll(m_donor), (uint32_t)__popcll(m_idle));
                 const bool donor = !done && sp > sb;
-                const uint32_t rank = (uint32_t)__popcll((donor ? m_donor : m_idle) & below);
+                const uint32_t rank = rank_below(donor ? m_donor : m_idle);
                 if (donor && rank < n_pairs) L.pair[rank] = lane;
                 __syncthreads();
                 const bool taker = done && rank < n_pairs;
@@ -877,8 +877,7 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
             if (at_leaf) { first = leaf_first(cur) + leaf_off; rem = leaf_count(cur) - leaf_off; }
             const uint32_t a = rem < 2u ? rem : 2u;
             const unsigned long long m2 = __ballot(a == 2u);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const uint32_t pos = tail + (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
+            const uint32_t pos = tail + rank_below(m1) + rank_below(m2);
             if (a >= 1u) L.ring[pos & (ANY_RING - 1u)] = first | (owner << 26);
             if (a == 2u) L.ring[(pos + 1u) & (ANY_RING - 1u)] = (first + 1u) | (owner << 26);
             tail += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
@@ -898,10 +897,9 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
             if (m_donor != 0ull) {
                 since_steal = 0u;
                 const unsigned long long m_idle = ~m_act;
-                const unsigned long long below = (1ull << lane) - 1ull;
                 const uint32_t n_pairs = min((uint32_t)__popcll(m_donor), (uint32_t)__popcll(m_idle));
                 const bool donor = !done && sp > sb;
-                const uint32_t rank = (uint32_t)__popcll((donor ? m_donor : m_idle) & below);
+                const uint32_t rank = rank_below(donor ? m_donor : m_idle);
                 if (donor && rank < n_pairs) L.pair[rank] = lane;
                 __syncthreads();
                 const bool taker = done && rank < n_pairs;
@@ -1050,8 +1048,7 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
             if (at_leaf) { first = leaf_first(cur) + leaf_off; rem = leaf_count(cur) - leaf_off; }
             const uint32_t a = rem < 2u ? rem : 2u;
             const unsigned long long m2 = __ballot(a == 2u);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const uint32_t pos = tail + (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
+            const uint32_t pos = tail + rank_below(m1) + rank_below(m2);
             if (a >= 1u) L.ring[pos & (ANY_RING - 1u)] = first | (ow << 25);
             if (a == 2u) L.ring[(pos + 1u) & (ANY_RING - 1u)] = (first + 1u) | (ow << 25);
             tail += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
@@ -1077,9 +1074,8 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
             const unsigned long long m_donor = __ballot(donor);
             if (m_donor != 0ull) {
                 const unsigned long long m_idle = ~m_act;
-                const unsigned long long below = (1ull << lane) - 1ull;
                 const uint32_t n_pairs = min((uint32_t)__popcll(m_donor), (uint32_t)__popcll(m_idle));
-                const uint32_t rank = (uint32_t)__popcll((donor ? m_donor : m_idle) & below);
+                const uint32_t rank = rank_below(donor ? m_donor : m_idle);
                 if (donor && rank < n_pairs) L.pair[rank] = lane;
                 __syncthreads();
                 const bool taker = done && rank < n_pairs;

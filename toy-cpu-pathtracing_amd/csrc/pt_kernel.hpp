@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             if (STATS) ts0 = __builtin_amdgcn_s_memtime();
             const unsigned long long m_needy = __ballot(!active);
             if (m_needy != 0ull && pool_next < pool_size) {
-                const uint32_t idx = pool_next + (uint32_t)__popcll(m_needy & ((1ull << lane) - 1ull));
+                const uint32_t idx = pool_next + rank_below(m_needy);
                 if (!active && idx < pool_size) {
                     const uint32_t pix = idx & ((1u << (2u * blk_log2)) - 1u);
                     const uint32_t px = job0.px + (pix & blk_mask), py = job0.py + (pix >> blk_log2);
