@@ -144,7 +144,7 @@ typedef struct mi355pt_stats {
     /* diagnostic (collect_stats only): wave-level step counts, to compare with the per-lane counts above
      * (lane utilisation of a stage = lane count / (64 * wave count)): 0 closest-hit node steps, 1 closest-hit triangle
      * steps, 2 any-hit node steps, 3 any-hit triangle steps, 4 iterations of the wave state machine, 5 lanes shaded
-     * (summed over iterations), 6 lanes with a shadow ray, 7 spare */
+     * (summed over iterations), 6 lanes with a shadow ray, 7 steal rounds of the merged traversal */
     uint64_t wave_steps[8];
     /* diagnostic (collect_stats = 2): how many lanes of the wave were still walking when a node step was issued — wave-level node
      * steps of the cooperative traversals by busy-lane count, bucket k = 8k+1 .. 8k+8 lanes; [0..7] closest-hit, [8..15] any-hit (where one traversal walks both kinds of ray, its steps are in [0..7]).  The

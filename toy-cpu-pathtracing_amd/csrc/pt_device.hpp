@@ -1073,6 +1073,7 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
             const bool donor = !done && (pend || sp > sb);
             const unsigned long long m_donor = __ballot(donor);
             if (m_donor != 0ull) {
+                if (STATS && lane == 0) st.w[7]++;       // steal rounds (mi355pt_stats.wave_steps[7])
                 const unsigned long long m_idle = ~m_act;
                 const uint32_t n_pairs = min((uint32_t)__popcll(m_donor), (uint32_t)__popcll(m_idle));
                 const uint32_t rank = rank_below(donor ? m_donor : m_idle);
