@@ -1,14 +1,17 @@
 #!/bin/bash
 # Static VALU instruction count of one compiled pt_kernel variant per source line (runs here: hipcc cross-compiles).
-# usage: tools/valu_by_line.sh <mis|nee|generic> <FEAT> [MODE]    e.g.  tools/valu_by_line.sh mis 1 1   (C2's kernel)
+# usage: tools/valu_by_line.sh <mis|nee|mis_cc|nee_cc|generic> <FEAT> [MODE]    e.g.  tools/valu_by_line.sh mis 1 1   (C2's kernel), nee_cc 4 2 (C5's)
 # Method: hipcc -gline-tables-only -S, then every v_* instruction is charged to the .loc line in effect (inlined callees are charged
 # to their own line: sqrtf / expf / sincosf show up under __clang_hip_math.h).  Static, not dynamic: a guide to what to look at.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 TU=$1; FEAT=$2; MODE=${3:-0}
+# <TU> = mis | nee | mis_cc | nee_cc | generic: the translation unit that holds the kernel (csrc/Makefile), compiled with that unit's backend options
 SRC=$R/toy-cpu-pathtracing_amd/csrc/pt_kernels$([ "$TU" = generic ] && echo "" || echo "_$TU").hip
 OUT=$(mktemp -d)
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -gline-tables-only -S --cuda-device-only -o $OUT/k.s $SRC 2>/dev/null
+OPT="-mllvm -disable-machine-licm"
+case $TU in mis|nee) OPT="$OPT -mllvm -sink-insts-to-avoid-spills=1 -mllvm -amdgpu-use-amdgpu-trackers=1";; mis_cc|nee_cc) OPT="$OPT -mllvm -sink-insts-to-avoid-spills=1";; esac
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off $OPT -gline-tables-only -S --cuda-device-only -o $OUT/k.s $SRC 2>/dev/null
 python3 - "$OUT/k.s" "_ZN2pt9pt_kernelILb0ELj${FEAT}ELj${MODE}EE" "$R/toy-cpu-pathtracing_amd/csrc/" <<'PY'
 import re, collections, sys, os
 path, sym, srcdir = sys.argv[1:4]
