@@ -643,6 +643,16 @@ def test_cpp_host_cli_matches_python_binding(product, pkg, tmp_path):
         assert cli.shape == ref.shape
         assert (np.abs(cli.astype(int) - ref.astype(int)) <= 1).mean() >= 0.999
         assert linear_rmse_u8(cli, ref) <= 1e-3
+    # the CLI's extension flags: --albedo-lut is mi355pt_params.albedo_lut, --gpus 1 is the single-device path
+    out = str(tmp_path / "cli_lut.png")
+    r = subprocess.run([exe, "--scene", "17", "--renderer", "nee", "--sampler", "sobol", "--spp", "8", "--width", "96", "--height", "64",
+                        "--albedo-lut", "--gpus", "1", "--output", out], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cli = np.asarray(Image.open(out).convert("RGB"))
+    sc = product.new_scene()
+    cam = pkg.scenes.load_scene(sc, 17, 96, 64)
+    ref = product.quantize_u8(product.render(sc, cam, pkg.make_params(8, "nee", "sobol", albedo_lut=1)))
+    assert (np.abs(cli.astype(int) - ref.astype(int)) <= 1).mean() >= 0.999
 
 
 def test_regression_runner_rehearsal(product, pkg, tmp_path):

@@ -12,11 +12,14 @@ using namespace renderer;
 struct Args {   // main.rs:20-53
     uint32_t scene = 0, spp = 64, seed = 0, width = 800, height = 600, max_depth = 16;
     std::string filter = "box", sampler = "random", renderer = "normal", output = "output.png";
+    // not in the reference's CLI: the coat-albedo table option (mi355pt_params.albedo_lut) and the number of GPUs of this node to shard the frame over
+    bool albedo_lut = false; int gpus = 1;
 };
 
 static void usage() {
     std::puts("Usage: mi355pt [--scene N] [-s|--spp N] [--seed N] [--filter box] [--sampler random|sobol]\n"
-              "               [--renderer normal|albedo|pt|nee|mis] [--width N] [--height N] [-d|--max-depth N] [-o|--output FILE]");
+              "               [--renderer normal|albedo|pt|nee|mis] [--width N] [--height N] [-d|--max-depth N] [-o|--output FILE]\n"
+              "       extensions: [--albedo-lut] (clearcoat albedo from its table instead of the 64-sample estimate)  [--gpus N]");
 }
 
 int main(int argc, char** argv) {
@@ -34,6 +37,8 @@ int main(int argc, char** argv) {
         else if (k == "--height") a.height = (uint32_t)std::stoul(val());
         else if (k == "-d" || k == "--max-depth") a.max_depth = (uint32_t)std::stoul(val());
         else if (k == "-o" || k == "--output") a.output = val();
+        else if (k == "--albedo-lut") a.albedo_lut = true;
+        else if (k == "--gpus") a.gpus = std::stoi(val());
         else if (k == "-h" || k == "--help") { usage(); return 0; }
         else { std::fprintf(stderr, "error: unexpected argument '%s'\n", k.c_str()); usage(); return 2; }
     }
@@ -67,7 +72,7 @@ int main(int argc, char** argv) {
         }
         std::puts("Start build scene.");                                                // main.rs:103-109
         auto t0 = std::chrono::steady_clock::now();
-        scene.build(camera);
+        if (a.gpus > 1) scene.build_multi(camera, a.gpus); else scene.build(camera);
         std::printf("Finish build scene: %.3f seconds.\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
         RendererArgs args{a.width, a.height, a.spp, a.seed, &scene, &camera};
@@ -79,10 +84,10 @@ int main(int argc, char** argv) {
         RendererImage image(a.width, a.height, r);
         std::puts("Start rendering...");                                                // main.rs:166-172
         t0 = std::chrono::steady_clock::now();
-        double kernel_s = image.render(a.sampler == "sobol" ? SamplerKind::ZSobol : SamplerKind::Random);
+        double kernel_s = image.render(a.sampler == "sobol" ? SamplerKind::ZSobol : SamplerKind::Random, a.albedo_lut);
         double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::printf("Finish rendering: %.3f seconds.\n", wall);
-        std::printf("(device %.3f s, %.1f Msamples/s)\n", kernel_s, (double)a.width * a.height * a.spp / kernel_s / 1e6);
+        if (kernel_s > 0.0) std::printf("(device %.3f s, %.1f Msamples/s)\n", kernel_s, (double)a.width * a.height * a.spp / kernel_s / 1e6);
         image.save(a.output);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "mi355pt: %s\n", e.what());

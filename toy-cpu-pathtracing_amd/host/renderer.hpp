@@ -670,6 +670,14 @@ public:
     void create_primitive(const SpotLightPrimitive& d) { add_light(MI355PT_LIGHT_SPOT, d.intensity, d.angle_inner, d.angle_outer, d.spectrum, d.transform); }
     void create_primitive(const DirectionalLightPrimitive& d) { add_light(MI355PT_LIGHT_DIRECTIONAL, d.intensity, 0, 0, d.spectrum, d.transform); }
     void build(const Camera& cam) { check(mi355pt_scene_build(s_, &cam.raw()), "mi355pt_scene_build"); }
+    // Scene::build over the first `n_devices` GPUs of the node (mi355pt_scene_build_multi): RendererImage::render then shards the frame
+    void build_multi(const Camera& cam, int n_devices) {
+        std::vector<int> ids((size_t)n_devices);
+        for (int i = 0; i < n_devices; ++i) ids[(size_t)i] = i;
+        check(mi355pt_scene_build_multi(s_, &cam.raw(), n_devices, ids.data()), "mi355pt_scene_build_multi");
+        multi_ = true;
+    }
+    bool multi() const { return multi_; }
     const mi355pt_scene* raw() const { return s_; }
 
 private:
@@ -689,6 +697,7 @@ private:
         mi355pt_spectrum s{}; s.kind = MI355PT_SPEC_TEXTURE_ALBEDO_SRGB; s.id = add_tex(*p.tex.img); return s;
     }
     mi355pt_scene* s_ = nullptr;
+    bool multi_ = false;
 };
 
 // ------------------------------------------------------------------ renderers (renderer/src/renderer.rs:84-149, main.rs:142-237)
@@ -703,10 +712,15 @@ class RendererImage {
 public:
     RendererImage(uint32_t w, uint32_t h, SrgbRenderer r) : pixels_((size_t)w * h * 3, 0.0f), w_(w), h_(h), r_(r) {}
     // RendererImage::render::<S>() — the seam: one call into the HIP library fills `pixels`
-    double render(SamplerKind sampler) {
+    // (albedo_lut: mi355pt_params.albedo_lut, an option outside the reference's CLI; 0 = the reference's estimator)
+    double render(SamplerKind sampler, bool albedo_lut = false) {
         mi355pt_params p{};
         p.spp = r_.args.spp; p.seed = r_.args.seed; p.max_depth = r_.max_depth; p.strategy = r_.strategy; p.sampler = (uint32_t)sampler;
-        p.exposure = r_.exposure; p.shard_index = 0; p.shard_count = 1;
+        p.exposure = r_.exposure; p.shard_index = 0; p.shard_count = 1; p.albedo_lut = albedo_lut ? 1u : 0u;
+        if (r_.args.scene->multi()) {                       // several GPUs from this one call: no per-launch statistics
+            check(mi355pt_render_multi(r_.args.scene->raw(), &r_.args.camera->raw(), &p, pixels_.data()), "mi355pt_render_multi");
+            return 0.0;
+        }
         mi355pt_stats st{};
         check(mi355pt_render(r_.args.scene->raw(), &r_.args.camera->raw(), &p, pixels_.data(), &st), "mi355pt_render");
         return st.kernel_ms * 1e-3;
