@@ -54,6 +54,22 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 #ifndef PT_ANY_DEFERRED
 #define PT_ANY_DEFERRED 1
 #endif
+// Wave priority by stage (s_setprio; the SIMD's issue arbitration goes by priority, then age): a wave in a traversal is a chain of dependent
+// round trips and loses nothing by yielding the issue port, a wave in the shading stage has independent work to issue — shading and hand-out
+// run at priority 3, traversals at 0: +0.9...+1.3 % (scenes 3 / 0 / 8 / 17; 0.0 on 15 / 19); the other way round -1.1 %.
+#ifndef PT_PRIO_TRAV
+#define PT_PRIO_TRAV 2             // 0: no priorities, 1: traversals high, 2: traversals low
+#endif
+#if PT_PRIO_TRAV == 1
+#define PT_PRIO_TRAV_ENTER __builtin_amdgcn_s_setprio(3)
+#define PT_PRIO_TRAV_EXIT __builtin_amdgcn_s_setprio(0)
+#elif PT_PRIO_TRAV == 2
+#define PT_PRIO_TRAV_ENTER __builtin_amdgcn_s_setprio(0)
+#define PT_PRIO_TRAV_EXIT __builtin_amdgcn_s_setprio(3)
+#else
+#define PT_PRIO_TRAV_ENTER ((void)0)
+#define PT_PRIO_TRAV_EXIT ((void)0)
+#endif
 // ONE cooperative traversal per iteration for the next closest-hit rays AND the light connections of the vertex just shaded (trace_pair_coop,
 // pt_device.hpp): a wave's step count is bounded by its deepest ray, not by the ray count, so the two traversals together cost ~20 node
 // steps instead of ~18 + ~14.  The price is the pending connection's 11 registers across one more stage.  Measured per kernel (same box):
@@ -216,14 +232,16 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 // ONE traversal for this iteration's closest-hit rays and the light connections the previous shading left pending
                 bool occluded = false;
                 if (STATS && sh.on) st.w[6]++;
+                PT_PRIO_TRAV_ENTER;
                 trace_pair_coop<STATS, wide_bvh<FEAT>()>(sc, P.ro, P.rd, active, sh.o, sh.d, sh.t, sh.on, stack, lane, pair_lds, hit, got, occluded, st);
+                PT_PRIO_TRAV_EXIT;
                 if (sh.on && !occluded) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
                 }
                 sh = ShadowReq{};      // consumed: every field dead from here on, for every lane — none of them is carried through the shading stage (+2 % on scenes 0 / 8)
             }
-            else got = trace_closest_coop<STATS, wide_bvh<FEAT>()>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st);
+            else { PT_PRIO_TRAV_ENTER; got = trace_closest_coop<STATS, wide_bvh<FEAT>()>(sc, P.ro, P.rd, active, stack, lane, closest_lds, hit, st); PT_PRIO_TRAV_EXIT; }
             if (STATS) {
                 // material divergence of the shading stage (mi355pt_stats.divergence): classes among the lanes that shade a surface
                 const uint32_t mclass = (active && got) ? sc.materials[__float_as_uint(((const float4*)(sc.shade + hit.tri))[4].z)].type : 8u;
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                     if (STATS && now) st.w[6]++;
                     bool occluded = false;
                     if (canonical) { if (now) occluded = trace_any<STATS>(sc, sh.o, sh.d, sh.t, stack, st); }
-                    else occluded = trace_any_deferred<STATS, wide_bvh<FEAT>()>(sc, sh.o, sh.d, sh.t, now, stack, lane, any_lds, st);
+                    else { PT_PRIO_TRAV_ENTER; occluded = trace_any_deferred<STATS, wide_bvh<FEAT>()>(sc, sh.o, sh.d, sh.t, now, stack, lane, any_lds, st); PT_PRIO_TRAV_EXIT; }
                     if (now && !occluded) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) P.L[i] = P.L[i] + sh.c[i];
