@@ -23,4 +23,5 @@ for n_lon, n_bands in SIZES:
     t3 = time.time()
     img = prod.render(sc, cam, pkg.make_params(16, "mis", "sobol"))
     t4 = time.time()
-    print(f"tris={m['idx'].reshape(-1,3).shape[0]} mesh_gen={t1-t0:.2f}s build={t3-t2:.2f}s render16spp={t4-t3:.2f}s info={prod.scene_info(sc)} mean={img.mean():.3f}", flush=True)
+    _, st = prod.render(sc, cam, pkg.make_params(1024, "mis", "sobol"), want_stats=True)
+    print(f"tris={m['idx'].reshape(-1,3).shape[0]} mesh_gen={t1-t0:.2f}s build={t3-t2:.2f}s render16spp={t4-t3:.2f}s Msamples_s_1024spp={640*360*1024/st.kernel_ms/1e3:.0f} info={prod.scene_info(sc)} mean={img.mean():.3f}", flush=True)

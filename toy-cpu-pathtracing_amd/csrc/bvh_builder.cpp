@@ -201,6 +201,96 @@ struct Collapse4 {
         return (int32_t)idx;
     }
 };
+
+// Cost-optimal collapse under the stack bound (dynamic programming, after Ylitie et al. 2017, sec. 4.1, with the budget as a third index).
+// Cost = sum of the surface areas of the 4-wide nodes' boxes (the expected number of node visits; a constant per node on top of the area was
+// swept and only loses); leaves are fixed.  b = stack slots free on
+// arrival at a node: a node with k children needs k - 1 of them and leaves b - (k - 1) to every child.
+//   root(n, b)    = A(n) + min over k in {2, 3, 4}, k - 1 <= b, and splits j + (k - j) of pack(left, j, b') + pack(right, k - j, b'),  b' = b - (k - 1)
+//   pack(n, i, b') = least cost of hanging n's subtree under the current node as at most i of its children:
+//                    leaf: 0;  i = 1: root(n, b');  else min(pack(n, i - 1, b'), min over j of pack(left, j, b') + pack(right, i - j, b'))
+struct CollapseDP {
+    const std::vector<DevNode>& n2;
+    std::vector<DevNode4>& out;
+    static constexpr int NB = STACK_DEPTH;                     // budgets 0 .. STACK_DEPTH - 1
+    std::vector<float> area, c_root, c_pack;                   // c_root[n][b], c_pack[n][i - 1][b] (i = 1..3)
+    std::vector<uint8_t> k_root, j_root, ch_pack;              // choices: k and the left share j of a root; for pack: 0 = use i - 1, else left share j
+    static constexpr float INF = 3.0e38f;
+    float& R(int32_t n, int b) { return c_root[(size_t)n * NB + (size_t)b]; }
+    float& P(int32_t n, int i, int b) { return c_pack[((size_t)n * 3 + (size_t)(i - 1)) * NB + (size_t)b]; }
+    uint8_t& PC(int32_t n, int i, int b) { return ch_pack[((size_t)n * 3 + (size_t)(i - 1)) * NB + (size_t)b]; }
+    float pack(int32_t link, int i, int b) { return link < 0 ? 0.0f : P(link, i, b); }
+    void solve(int32_t root) {
+        const size_t n = n2.size();
+        area.assign(n, 0.0f); c_root.assign(n * NB, INF); c_pack.assign(n * 3 * NB, INF);
+        k_root.assign(n * NB, 0); j_root.assign(n * NB, 0); ch_pack.assign(n * 3 * NB, 0);
+        // post-order without recursion limits: children have larger construction indices than their parents in both builders? not guaranteed
+        std::vector<int32_t> order; order.reserve(n);
+        std::vector<int32_t> st{root};
+        while (!st.empty()) { int32_t v = st.back(); st.pop_back(); order.push_back(v); for (int c = 0; c < 2; ++c) if (n2[(size_t)v].child[c] >= 0) st.push_back(n2[(size_t)v].child[c]); }
+        for (size_t q = order.size(); q-- > 0;) {
+            const int32_t v = order[q];
+            const DevNode& nd = n2[(size_t)v];
+            const float lo[3] = {std::min(nd.bx[0], nd.bx[1]), std::min(nd.by[0], nd.by[1]), std::min(nd.bz[0], nd.bz[1])};
+            const float hi[3] = {std::max(nd.bx[2], nd.bx[3]), std::max(nd.by[2], nd.by[3]), std::max(nd.bz[2], nd.bz[3])};
+            const float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+            area[(size_t)v] = 2.0f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+            const int32_t l = nd.child[0], r = nd.child[1];
+            for (int b = 0; b < NB; ++b) {                      // this node as the root of a 4-wide node arriving with b free slots
+                float best = INF; int bk = 0, bj = 0;
+                for (int k = 2; k <= 4 && k - 1 <= b; ++k) {
+                    const int bb = b - (k - 1);
+                    for (int j = 1; j < k; ++j) {
+                        if (j > 3 || k - j > 3) continue;
+                        const float c = pack(l, j, bb) + pack(r, k - j, bb);
+                        if (c < best) { best = c; bk = k; bj = j; }
+                    }
+                }
+                if (best < INF) { R(v, b) = area[(size_t)v] + best; k_root[(size_t)v * NB + (size_t)b] = (uint8_t)bk; j_root[(size_t)v * NB + (size_t)b] = (uint8_t)bj; }
+            }
+            for (int b = 0; b < NB; ++b) {                      // this node's subtree hung under a node whose children have b free slots
+                P(v, 1, b) = R(v, b); PC(v, 1, b) = 0;
+                for (int i = 2; i <= 3; ++i) {
+                    float best = P(v, i - 1, b); int bj = 0;
+                    for (int j = 1; j < i; ++j) {
+                        const float c = pack(l, j, b) + pack(r, i - j, b);
+                        if (c < best) { best = c; bj = j; }
+                    }
+                    P(v, i, b) = best; PC(v, i, b) = (uint8_t)bj;
+                }
+            }
+        }
+    }
+    using Member = Collapse4::Member;
+    void collect(const Member& m, int i, int b, std::vector<Member>& into) {
+        if (m.link < 0 || i == 1) { into.push_back(m); return; }
+        const int j = PC(m.link, i, b);
+        if (j == 0) { collect(m, i - 1, b, into); return; }
+        const DevNode& e = n2[(size_t)m.link];
+        collect(Collapse4::member(e, 0), j, b, into);
+        collect(Collapse4::member(e, 1), i - j, b, into);
+    }
+    int32_t emit(int32_t link2, int b) {
+        if (link2 < 0) return link2;
+        const int k = k_root[(size_t)link2 * NB + (size_t)b], j = j_root[(size_t)link2 * NB + (size_t)b];
+        const DevNode& e = n2[(size_t)link2];
+        std::vector<Member> m;
+        collect(Collapse4::member(e, 0), j, b - (k - 1), m);
+        collect(Collapse4::member(e, 1), k - j, b - (k - 1), m);
+        const size_t idx = out.size();
+        out.emplace_back();
+        int32_t links[4] = {0, 0, 0, 0};
+        for (size_t c = 0; c < m.size(); ++c) links[c] = emit(m[c].link, b - (k - 1));
+        DevNode4& d = out[idx];
+        for (int c = 0; c < 4; ++c) {
+            const bool used = (size_t)c < m.size();
+            d.lox[c] = used ? m[(size_t)c].lo[0] : FLT_MAX; d.loy[c] = used ? m[(size_t)c].lo[1] : FLT_MAX; d.loz[c] = used ? m[(size_t)c].lo[2] : FLT_MAX;
+            d.hix[c] = used ? m[(size_t)c].hi[0] : FLT_MAX; d.hiy[c] = used ? m[(size_t)c].hi[1] : FLT_MAX; d.hiz[c] = used ? m[(size_t)c].hi[2] : FLT_MAX;
+            d.child[c] = used ? links[c] : 0; d.pad[c] = 0;
+        }
+        return (int32_t)idx;
+    }
+};
 }  // namespace
 
 bool collapse_bvh4(const std::vector<DevNode>& nodes2, int32_t root2, size_t n_tris, std::vector<DevNode4>* nodes4, int32_t* root4, int* max_stack,
@@ -210,7 +300,19 @@ bool collapse_bvh4(const std::vector<DevNode>& nodes2, int32_t root2, size_t n_t
     Collapse4 col{nodes2, *nodes4, std::vector<int>(nodes2.size(), 0)};
     col.compute_height(root2);
     if (root2 < 0 || col.height_of(root2) >= STACK_DEPTH) { *err = "BVH deeper than the traversal stack"; return false; }
-    *root4 = col.emit(root2, STACK_DEPTH - 1);
+    // the cost-optimal collapse where its tables fit (24 budgets x 4 entries per binary node), the greedy one otherwise and for the wrapped
+    // single-leaf root; MI355PT_BVH_COLLAPSE=greedy|dp in a -DMI355PT_TUNING build for A/B runs
+    bool use_dp = nodes2.size() >= 2 && nodes2.size() <= 1200000;
+#ifdef MI355PT_TUNING
+    if (const char* e = getenv("MI355PT_BVH_COLLAPSE")) use_dp = use_dp && std::string(e) != "greedy";
+#endif
+    if (use_dp) {
+        CollapseDP dp{nodes2, *nodes4};
+        dp.solve(root2);
+        if (dp.R(root2, STACK_DEPTH - 1) < CollapseDP::INF) *root4 = dp.emit(root2, STACK_DEPTH - 1);
+        else use_dp = false;
+    }
+    if (!use_dp) { nodes4->clear(); *root4 = col.emit(root2, STACK_DEPTH - 1); }
     // the guarantees the kernel relies on, checked on the tree that is uploaded: links in range, no cycle, every triangle in exactly one
     // leaf, worst-case pending siblings along any path (= the per-lane LDS stack need) below STACK_DEPTH
     size_t tris_seen = 0, visited = 0;

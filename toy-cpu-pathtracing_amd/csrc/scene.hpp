@@ -67,6 +67,7 @@ struct SceneImpl {
     size_t bvh4_nodes = 0;        // nodes of the collapsed tree (DevNode4)
     int bvh_builder = 0;          // MI355PT_BVH_AUTO / _HOST / _GPU (mi355pt_scene_set_bvh_builder)
     int bvh_builder_used = 1;     // what build() took
+    double collapse_ms = 0.0;     // host time of the 2-wide -> 4-wide collapse
     double bvh_build_ms = 0.0;    // wall time of the BVH build inside build(); bvh_device_ms: device part of a GPU build
     double bvh_device_ms = 0.0;
     uint32_t features = FEAT_ALL;   // FEAT_* bits the scene's materials need (kernel specialisation)
