@@ -72,16 +72,24 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
 #endif
 // ONE cooperative traversal per iteration for the next closest-hit rays AND the light connections of the vertex just shaded (trace_pair_coop,
 // pt_device.hpp): a wave's step count is bounded by its deepest ray, not by the ray count, so the two traversals together cost ~20 node
-// steps instead of ~18 + ~14.  The price is the pending connection's 11 registers across one more stage.  Measured per kernel (same box):
-// kernels without the clearcoat code +2.4...+5 % (scene 3 1 716 -> 1 757, scene 0 1 814 -> 1 906, scene 8 1 525 -> 1 574, scene 10 1 519 -> 1 583);
-// clearcoat kernels (3 waves per SIMD) in the MIS specialisation +1.7 / +5.5 % (scenes 15 / 19), in the NEE specialisation -1.9 % (scene 17:
-// C5's kernel, scratch 88 -> 144 B per lane) — that one, and the generic-mode clearcoat kernels (not measured), keep the two traversals.
+// steps instead of ~18 + ~14.  The price is the pending connection's 11 registers across one more stage, and a heavier loop where there
+// are no connections at all.  Measured per kernel (same box):
+//   kernels without the clearcoat code: +2.4...+5 % (scene 3 1 716 -> 1 757, scene 0 1 814 -> 1 906, scene 8 1 525 -> 1 574, scene 10 1 519 -> 1 583);
+//   clearcoat kernels (3 waves per SIMD), with the LDS parking and the sinking in place: MIS +1.7 / +5.5 % (scenes 15 / 19); NEE +2.2 % (scene 17,
+//   C5's kernel: 1 242 -> 1 270), +2.2 / +3.6 % (scenes 16 / 20), +1.5 % (scene 19) — but -1.1 / -2.1 % in the clearcoat + texture set under NEE or
+//   the generic mode (scenes 15 / 18), which keeps two traversals;
+//   the plain path tracer (strategy pt: no connections exist) loses 9 % with it (scene 3 2 790 vs 2 557): it has its own specialisation
+//   (MODE_PT, pt_kernels_pt.hip) without it; choosing inside one kernel at run time costs both sides (-5 % / -8 %: measured);
+//   generic-mode clearcoat kernels (random sampler with NEE / MIS): not measured, two traversals as before.
 #ifndef PT_MERGED_TRAVERSAL
 #define PT_MERGED_TRAVERSAL 1      // 0: never, 1: as measured (above), 2: every kernel
 #endif
-enum : uint32_t { MODE_GENERIC = 0, MODE_MIS_SOBOL = 1, MODE_NEE_SOBOL = 2 };
+enum : uint32_t { MODE_GENERIC = 0, MODE_MIS_SOBOL = 1, MODE_NEE_SOBOL = 2, MODE_PT = 3 };
 template <uint32_t FEAT, uint32_t MODE> constexpr bool merged_traversal() {
-    return PT_MERGED_TRAVERSAL == 2 || (PT_MERGED_TRAVERSAL == 1 && ((FEAT & FEAT_CC) == 0u || MODE == MODE_MIS_SOBOL));
+    if (PT_MERGED_TRAVERSAL != 1) return PT_MERGED_TRAVERSAL == 2;
+    if (MODE == MODE_PT) return false;
+    if ((FEAT & FEAT_CC) == 0u || MODE == MODE_MIS_SOBOL) return true;
+    return MODE == MODE_NEE_SOBOL && FEAT != (FEAT_CC | FEAT_TEX);
 }
 #ifndef PT_CLOSEST_COOP
 #define PT_CLOSEST_COOP 1      // needs PT_ANY_DEFERRED (shares its LDS ring)
@@ -132,6 +140,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     DevParams prm = prm_in;
     if constexpr (MODE == MODE_MIS_SOBOL) { prm.strategy = 2u; prm.sampler = 1u; }
     if constexpr (MODE == MODE_NEE_SOBOL) { prm.strategy = 1u; prm.sampler = 1u; }
+    if constexpr (MODE == MODE_PT) prm.strategy = 0u;                      // either sampler
     const uint32_t lane = threadIdx.x;
     auto park = [&](Path& Q) {
         if constexpr (PARK) {
@@ -387,5 +396,6 @@ void launch_pt_mis_sobol(const PtLaunchArgs& a, uint32_t feat);      // pt_kerne
 void launch_pt_mis_sobol_cc(const PtLaunchArgs& a, uint32_t feat);   // pt_kernels_mis_cc.hip
 void launch_pt_nee_sobol(const PtLaunchArgs& a, uint32_t feat);      // pt_kernels_nee.hip
 void launch_pt_nee_sobol_cc(const PtLaunchArgs& a, uint32_t feat);   // pt_kernels_nee_cc.hip
+void launch_pt_strategy_pt(const PtLaunchArgs& a, uint32_t feat);    // pt_kernels_pt.hip (the plain path tracer, either sampler)
 
 }  // namespace pt

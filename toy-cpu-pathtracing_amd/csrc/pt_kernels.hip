@@ -148,6 +148,7 @@ hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& 
             hipLaunchKernelGGL((pt_kernel<true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout);
     } else if (prm.sampler == 1u && prm.strategy == 2u) launch_pt_mis_sobol(a, feat);
     else if (prm.sampler == 1u && prm.strategy == 1u) launch_pt_nee_sobol(a, feat);
+    else if (prm.strategy == 0u) launch_pt_strategy_pt(a, feat);
     else launch_pt_mode<MODE_GENERIC>(a, feat);
     if (prm.chunks > 1) {
         const uint32_t n_tiles = (prm.n_work / prm.chunks) >> (6u - 2u * prm.block_log2);   // n_work = tiles * blocks per tile * chunks
