@@ -613,11 +613,19 @@ PT_DEV Node4Hits node4_step(const DevNode4* nodes, int32_t cur, f3 ro, f3 inv, f
     h.link[0] = ch.x; h.link[1] = ch.y; h.link[2] = ch.z; h.link[3] = ch.w;
     return h;
 }
-// ascending by entry distance (5 compare-exchanges); misses (+inf) end up last
+// nearest child to slot 0 (PT_SORT_MODE 1) or ascending by entry distance (0); misses (+inf) are skipped by the pushes
+#ifndef PT_SORT_MODE
+#define PT_SORT_MODE 1      // 0: full sorting network (5 compare-exchanges); 1: nearest child first, the rest in slot order (3): the
+                            // later pops are a little less well ordered, the step is 16 instructions shorter: +0.4...+0.7 %
+#endif
 PT_DEV void sort4(Node4Hits& h) {
 #define PT_CSWAP(a, b) { const bool s = h.n[b] < h.n[a]; const float tn = s ? h.n[b] : h.n[a]; const float tx = s ? h.n[a] : h.n[b]; \
                          const int32_t ln = s ? h.link[b] : h.link[a]; const int32_t lx = s ? h.link[a] : h.link[b]; h.n[a] = tn; h.n[b] = tx; h.link[a] = ln; h.link[b] = lx; }
+#if PT_SORT_MODE == 1
+    PT_CSWAP(0, 1) PT_CSWAP(0, 2) PT_CSWAP(0, 3)          // the minimum to slot 0; misses (+inf) among 1..3 are skipped by the pushes
+#else
     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#endif
 #undef PT_CSWAP
 }
 
