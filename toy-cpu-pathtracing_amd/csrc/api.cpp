@@ -22,7 +22,7 @@ hipError_t launch_probe_sobol(uint32_t, uint32_t, uint32_t, uint32_t, const uint
 hipError_t launch_probe_intersect(const DevScene&, const float*, const float*, uint32_t, float*, uint32_t*, uint32_t*, float*, hipStream_t);
 hipError_t launch_probe_occluded(const DevScene&, const float*, const float*, const float*, uint32_t, uint8_t*, hipStream_t);
 uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed);
-int query_resident_waves(uint32_t feat);
+int query_resident_waves(bool stats, uint32_t feat, uint32_t sampler, uint32_t strategy);
 }  // namespace pt
 
 using namespace pt;
@@ -44,6 +44,8 @@ static const uint32_t CIE_CMF_BITS[470 * 4] = {
 // counters / stats blocks so that back-to-back asynchronous launches never share a counter.
 constexpr int CTX_RING = 16;
 struct LaunchCtx {
+    int device = -1;                  // the device every buffer below lives on (= SceneImpl::device when the context was made)
+    int waves[2][2][3] = {{{0}}};     // [instrumented][sampler][strategy]: resident waves of the kernel that combination launches (0: not asked yet)
     uint64_t* d_hash = nullptr;
     uint32_t hash_seed = 0;
     bool hash_valid = false;
@@ -52,7 +54,13 @@ struct LaunchCtx {
     float* d_partial = nullptr;       // per-chunk film tiles of split launches (tiles * chunks * 64 * 3 floats), grown on demand;
     size_t partial_floats = 0;        // reused by consecutive launches: one stream at a time per scene
     int next = 0;
-    ~LaunchCtx() { (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); (void)hipFree(d_partial); }
+    ~LaunchCtx() {
+        // freed with the owning device current (a scene rebuilt on another device drops its context from there)
+        int cur = -1;
+        const bool swap = device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+        (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); (void)hipFree(d_partial);
+        if (swap) (void)hipSetDevice(cur);
+    }
 };
 // One device's share of a multi-device scene (mi355pt_scene_build_multi): a full replica of the scene on that device plus
 // the stream, film and event mi355pt_render_multi drives it with.  Replica 0 is the scene object itself.
@@ -130,10 +138,10 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
 };
 
-int resident_waves(uint32_t feat) {
-    static int cached[512] = {0};
-    int& c = cached[feat & 511u];
-    if (!c) c = query_resident_waves(feat);
+// the persistent grid of the exact (instrumented?, sampler, strategy) kernel of this scene's feature set on this scene's device
+int resident_waves(LaunchCtx* lc, bool stats, uint32_t feat, uint32_t sampler, uint32_t strategy) {
+    int& c = lc->waves[stats ? 1 : 0][sampler & 1u][strategy < 3u ? strategy : 0u];
+    if (!c) c = query_resident_waves(stats, feat, sampler, strategy);
     return c;
 }
 
@@ -156,8 +164,15 @@ DevParams make_params(const mi355pt_camera* cam, const mi355pt_params* p, uint32
 
 // returns the scene's launch context with the hash table valid for `seed`; `slot` receives a fresh ring slot
 int get_launch_ctx(const mi355pt_scene* sc, uint32_t seed, hipStream_t stream, LaunchCtx** out, int* slot) {
+    // (check_args has made sure that the current device is the one the scene was built on)
+    if (sc->ctx && sc->ctx->device != sc->impl.device) {
+        // the scene was rebuilt on another device since its last render (mi355pt_scene_build after hipSetDevice, or build_multi with a
+        // different first device): the hash table, counters, stats and partial film of the old context live in the OLD device's memory
+        delete sc->ctx; sc->ctx = nullptr;
+    }
     if (!sc->ctx) {
         LaunchCtx* lc = new LaunchCtx();
+        lc->device = sc->impl.device;
         HIP_TRY(hipMalloc((void**)&lc->d_hash, sizeof(uint64_t) * HASH_TABLE_DIMS));
         HIP_TRY(hipMalloc((void**)&lc->d_counters, sizeof(unsigned) * CTX_RING));
         HIP_TRY(hipMalloc((void**)&lc->d_stats, sizeof(DevStats) * CTX_RING));
@@ -386,6 +401,9 @@ int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam) {
     float cmf[470 * 4];
     std::memcpy(cmf, CIE_CMF_BITS, sizeof(cmf));
     int rc = s->impl.build(cam, cmf, &err);
+    // the launch context belongs to the old build: another feature set launches other kernels (cached grid sizes), another device makes its
+    // buffers foreign memory — get_launch_ctx makes a new one, on the build's device, at the next render
+    delete s->ctx; s->ctx = nullptr;
     return rc ? fail(rc, err) : MI355PT_OK;
 }
 
@@ -411,8 +429,10 @@ static int render_accum_range(const mi355pt_scene* s, const mi355pt_camera* cam,
     uint32_t n_tiles_total = dp.tiles_x * dp.tiles_y;
     uint32_t n_tiles = n_tiles_total > dp.shard_index ? (n_tiles_total - dp.shard_index + dp.shard_count - 1) / dp.shard_count : 0;
     if (n_tiles == 0) return MI355PT_OK;
-    // (the instrumented variants: every feature but clearcoat / textured emitters when the scene has neither, else the all-features kernel)
-    int waves = resident_waves((stats && p->collect_stats) ? ((s->impl.features & (FEAT_CC | FEAT_EMTEX)) == 0u ? (uint32_t)(FEAT_STD & ~FEAT_CC) : (uint32_t)FEAT_ALL) : s->impl.features);
+    LaunchCtx* lc; int slot;
+    if ((rc = get_launch_ctx(s, p->seed, stream, &lc, &slot))) return rc;
+    if (lc->device != s->impl.device) return fail(MI355PT_E_DEVICE, "launch context and scene live on different devices");
+    int waves = resident_waves(lc, stats && p->collect_stats, s->impl.features, dp.sampler, dp.strategy);
     // Work items.  A work item is a 2^b x 2^b pixel block of an 8x8 tile times a range of sample indices, its (pixel, sample)
     // pairs handed to the lanes as a pool.  Sobol: the fewer pixels an item has, the fewer Morton digits vary inside it, and only
     // varying digits (minus the two that have block-level tables) are hashed per draw (pt_device.hpp sampler_index): take the
@@ -460,8 +480,6 @@ static int render_accum_range(const mi355pt_scene* s, const mi355pt_camera* cam,
         if ((1u << (2u * m)) == cs && s_begin % cs == 0 && m >= 3 && m <= dp.log2_spp / 2u &&
             2u * dp.n_base4_digits <= 2u * m + 27u) dp.sample_prefix_digits = dp.log2_spp / 2u - m;   // prefix above bit 2m must fit 27 bits
     }
-    LaunchCtx* lc; int slot;
-    if ((rc = get_launch_ctx(s, p->seed, stream, &lc, &slot))) return rc;
     unsigned* d_counter = lc->d_counters + slot;
     DevStats* d_stats = lc->d_stats + slot;
     HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned), stream));

@@ -52,6 +52,15 @@ struct alignas(16) DevNode4 {
     uint32_t pad[4];
 };
 static_assert(sizeof(DevNode4) == 128, "wide node must be 128 B");
+// PT_NODE_FMA 1: the slab distances of the 4-wide step are ONE fma per plane, plane * (1/d) + (-(o * (1/d))), instead of a subtraction and a
+// multiplication ((plane - o) * (1/d)).  The fma form cancels: its absolute error is u * |o / d| + u * |t| (u = 2^-24), i.e. up to 2 u * max(|o|, |plane|)
+// measured in space, where the two-step form has 2 u * |t|.  The host therefore pads every box of the DevNode4 tree by NODE4_PAD_REL x the largest
+// coordinate magnitude of the scene (16 x that bound) when it uploads the tree (scene.cpp): the padded test can only visit MORE nodes than the
+// exact one, and which triangle a ray hits is decided by the unchanged watertight triangle test.  The BVH2 records (probes, canonical counts) stay exact.
+#ifndef PT_NODE_FMA
+#define PT_NODE_FMA 0
+#endif
+constexpr float NODE4_PAD_REL = 9.5367431640625e-07f;   // 2^-20
 PT_HD inline int32_t make_leaf(uint32_t first, uint32_t count) { return (int32_t)(0x80000000u | (first << 3) | (count - 1)); }
 PT_HD inline uint32_t leaf_first(int32_t c) { return ((uint32_t)c & 0x7fffffffu) >> 3; }
 PT_HD inline uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1; }

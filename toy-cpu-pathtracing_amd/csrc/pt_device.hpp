@@ -589,13 +589,50 @@ PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* s
 }
 
 // One step through the collapsed tree (layout.hpp DevNode4): slab tests of up to four child boxes.  n[c] = entry distance of child c, or
-// +inf if the ray misses it (unused slots hold an inverted infinite box and miss by themselves).
+// +inf if the ray misses it.  Unused slots hold a POINT box at +FLT_MAX (bvh_builder.cpp collapse_bvh4): its slab distances are
+// +-FLT_MAX * |1/d| (|1/d| >= 1 for a unit direction), outside [0, t_lim] as long as t_lim <= 1e30: the callers' contract, see below.
 struct Node4Hits { float n[4]; int32_t link[4]; };
+// PT_NODE_SEL 1: the NEAR and FAR plane of every slab are chosen by the sign of the ray direction through the LOAD ADDRESS (the node keeps
+// lo and hi planes of an axis as two consecutive float4: near = the one at +16 B when 1/d is negative) instead of by a min / max pair per
+// child and axis after the fact: (lo - o) * inv <= (hi - o) * inv exactly when inv > 0 (rounding is monotonic), so the values are the ones
+// min / max produced, for 24 VALU instructions less per node step (of ~125).  0: the min / max form.
+#ifndef PT_NODE_SEL
+#define PT_NODE_SEL 1
+#endif
 PT_DEV Node4Hits node4_step(const DevNode4* nodes, int32_t cur, f3 ro, f3 inv, float t_lim) {
+    // CONTRACT: t_lim <= 1e30 (every caller clamps its limit once per ray, not once per step: trace_any_deferred / trace_closest_coop /
+    // trace_pair_coop initialise and only ever shrink w_t / w_tmax / w_tbest from min(t, 1e30)).
+    float n0, n1, n2, n3, f0, f1, f2, f3_;
+#if PT_NODE_SEL
+    const char* base = (const char*)nodes;
+    const uint32_t o = (uint32_t)cur << 7;
+    const uint32_t ox = o + ((__float_as_uint(inv.x) >> 27) & 16u), oy = o + ((__float_as_uint(inv.y) >> 27) & 16u), oz = o + ((__float_as_uint(inv.z) >> 27) & 16u);
+    const float4 ax = *(const float4*)(base + ox), bx = *(const float4*)(base + (ox ^ 16u));
+    const float4 ay = *(const float4*)(base + 32 + oy), by = *(const float4*)(base + 32 + (oy ^ 16u));
+    const float4 az = *(const float4*)(base + 64 + oz), bz = *(const float4*)(base + 64 + (oz ^ 16u));
+    const int4 ch = *(const int4*)(base + 96 + o);
+    // all seven loads of the node are issued before the first slab is evaluated: left alone, the scheduler sinks the links' load below the
+    // box arithmetic (fewer live registers) and the step then waits for a SECOND L1 round trip at its very end
+#ifndef PT_NODE_LOADS_FIRST
+#define PT_NODE_LOADS_FIRST 1
+#endif
+#if PT_NODE_LOADS_FIRST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#if PT_NODE_FMA     // `ro` holds -(o * inv) (walk_origin below), the boxes are padded by the host: layout.hpp
+#define PT_SLAB(C, N, F) N = fmaxf(fmaxf(fmaxf(fmaf(ax.C, inv.x, ro.x), fmaf(ay.C, inv.y, ro.y)), fmaf(az.C, inv.z, ro.z)), 0.0f); \
+                         F = fminf(fminf(fminf(fmaf(bx.C, inv.x, ro.x), fmaf(by.C, inv.y, ro.y)), fmaf(bz.C, inv.z, ro.z)), t_lim);
+#else
+#define PT_SLAB(C, N, F) N = fmaxf(fmaxf(fmaxf((ax.C - ro.x) * inv.x, (ay.C - ro.y) * inv.y), (az.C - ro.z) * inv.z), 0.0f); \
+                         F = fminf(fminf(fminf((bx.C - ro.x) * inv.x, (by.C - ro.y) * inv.y), (bz.C - ro.z) * inv.z), t_lim);
+#endif
+    PT_SLAB(x, n0, f0) PT_SLAB(y, n1, f1) PT_SLAB(z, n2, f2) PT_SLAB(w, n3, f3_)
+#undef PT_SLAB
+#else
     const float4* q = (const float4*)(nodes + cur);
     // axis by axis: the interval of each child narrows as its x, y, z slabs arrive (max / min are exact, so the order does not change a
     // result); two float4 of planes are live at a time instead of six — the traversal loop sits inside the register budget of the path state
-    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f, f0 = t_lim, f1 = t_lim, f2 = t_lim, f3_ = t_lim;
+    n0 = 0.0f; n1 = 0.0f; n2 = 0.0f; n3 = 0.0f; f0 = t_lim; f1 = t_lim; f2 = t_lim; f3_ = t_lim;
 #define PT_AXIS4(LO, HI, O, I)                                                                                              \
     {                                                                                                                       \
         const float4 lo = q[LO], hi = q[HI];                                                                                \
@@ -608,10 +645,20 @@ PT_DEV Node4Hits node4_step(const DevNode4* nodes, int32_t cur, f3 ro, f3 inv, f
     PT_AXIS4(0, 1, ro.x, inv.x) PT_AXIS4(2, 3, ro.y, inv.y) PT_AXIS4(4, 5, ro.z, inv.z)
 #undef PT_AXIS4
     const int4 ch = *(const int4*)(q + 6);
+#endif
     Node4Hits h;
     h.n[0] = n0 <= f0 ? n0 : INFINITY; h.n[1] = n1 <= f1 ? n1 : INFINITY; h.n[2] = n2 <= f2 ? n2 : INFINITY; h.n[3] = n3 <= f3_ ? n3 : INFINITY;
     h.link[0] = ch.x; h.link[1] = ch.y; h.link[2] = ch.z; h.link[3] = ch.w;
     return h;
+}
+// what a walking lane keeps as the "origin" of its ray: the origin itself, or with PT_NODE_FMA in the 4-wide tree the slab addend -(o * 1/d)
+#if PT_NODE_FMA && !PT_NODE_SEL
+#error "PT_NODE_FMA needs PT_NODE_SEL"
+#endif
+template <bool WIDE>
+PT_DEV f3 walk_origin(f3 ro, f3 inv) {
+    if (WIDE && PT_NODE_FMA) return mk3(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
+    return ro;
 }
 // nearest child to slot 0 (PT_SORT_MODE 1) or ascending by entry distance (0); misses (+inf) are skipped by the pushes
 // stack pushes of the 4-wide step as stores-always / advance-conditionally: a slot written for a miss lies above the top and is never read
@@ -668,7 +715,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
     // the ray this lane is WALKING (its own, or one it is helping with) — the lane's own ray stays in ro/rd/rs for the flushes
     // (box tests only see distances up to 1e30: the unused slots of a DevNode4 are point boxes at FLT_MAX, whose slab distance FLT_MAX / |d|
     // must never fall inside [0, t_lim] — an unbounded shadow ray (t_max = FLT_MAX, directional and environment lights) would let it)
-    f3 w_ro = ro, w_inv = rs.inv; float w_tmax = fminf(t_max, 1e30f); uint32_t owner = lane;
+    f3 w_ro = walk_origin<WIDE>(ro, rs.inv), w_inv = rs.inv; float w_tmax = fminf(t_max, 1e30f); uint32_t owner = lane;
     int sp = 0, sb = 0;
     int32_t cur = WIDE ? sc.root4 : sc.root;
     uint32_t leaf_off = 0;                    // triangles of the current leaf already queued
@@ -815,7 +862,7 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
     const uint32_t kpack = (uint32_t)rs.kx | ((uint32_t)rs.ky << 2) | ((uint32_t)rs.kz << 4);
     L.best[lane] = (0x7f7fffffull << 32) | 0xffffffffull;                 // (FLT_MAX, no triangle)
     __syncthreads();
-    f3 w_ro = ro, w_inv = rs.inv; float w_tbest = 1e30f; uint32_t owner = lane;             // box-test limit, see trace_any_deferred
+    f3 w_ro = walk_origin<WIDE>(ro, rs.inv), w_inv = rs.inv; float w_tbest = 1e30f; uint32_t owner = lane;             // box-test limit, see trace_any_deferred
     int sp = 0, sb = 0;
     int32_t cur = WIDE ? sc.root4 : sc.root;
     uint32_t leaf_off = 0;
@@ -974,32 +1021,78 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
 #define PT_PRIO_FLUSH_ENTER ((void)0)
 #define PT_PRIO_FLUSH_EXIT ((void)0)
 #endif
-struct PairLds { uint32_t* ring; unsigned long long* best; uint32_t* occl; uint32_t* pair; };   // ring[ANY_RING], best[64], occl[2], pair[64]
+struct PairLds { uint32_t* ring; unsigned long long* best; uint32_t* occl; uint32_t* pair; uint32_t* infl; };   // ring[ANY_RING], best[64], occl[2], pair[64], infl[2]
 constexpr uint32_t RAY_ANY = 64u;             // kind bit of a ray id
 
-template <bool STATS, bool WIDE>
+// STRAGGLER CARRY-OVER (CARRY > 0).  A lock-step wave pays for its deepest ray: a fifth of the merged traversal's node steps run with at most 8
+// of 64 lanes still walking a chain of dependent fetch -> test round trips that no amount of stealing shortens.  With CARRY = n
+// the traversal RETURNS when at most n lanes are still walking and all of them are on closest-hit rays with nothing pending: each of those
+// lanes saves its walking context (node link, stack window, working ray, owner: CTX_DWORDS dwords, compacted by rank into the LDS ring, which
+// is empty between calls) — the stack entries stay where they are, in the lane's own LDS column — and the OWNERS of the unfinished rays are
+// reported in `c_inflight`: such a lane skips its shading stage (its path state is untouched, its best-hit key stays in LDS) and passes
+// `c_resume` to the next call, in which the saved contexts walk on beside the next iteration's fresh rays.  The wave's other lanes shade,
+// regenerate and trace meanwhile instead of idling through the tail.  Shadow rays are never carried: a connection's contribution would have to
+// wait in registers through the shading stage (measured: -2...-6 %), so the exit waits until no lane walks or holds a shadow ray.
+// Results do not change: every ray is walked over exactly the same subtrees with the same merges, only in a different call.
+struct CarryState { unsigned long long walk; };      // wave-uniform: the lanes that hold a saved walking context (slot = rank within the mask)
+constexpr uint32_t CTX_DWORDS = 10u;
+#ifndef PT_CARRY_MIN_FRESH
+#define PT_CARRY_MIN_FRESH 32    // the early return is allowed only in calls that started at least this many fresh closest-hit rays (a wave
+                                 // that is draining its work item must not leave the traversal after every step)
+#endif
+
+// PT_SHADOW_FIRST: a lane with both rays walks its SHADOW ray first and keeps the closest-hit ray pending (the other way round by default).
+// Shadow rays cannot be carried over, closest-hit rays can: with the shadow rays started first the traversal's tail consists of closest-hit
+// rays, which is what the carry-over needs to find there.
+#ifndef PT_SHADOW_FIRST
+#define PT_SHADOW_FIRST 0
+#endif
+template <bool STATS, bool WIDE, int CARRY = 0>
 PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f3 s_ro, f3 s_rd, float s_tmax, bool s_want, uint32_t* stack,
-                            uint32_t lane, const PairLds& L, Hit& hit, bool& c_found, bool& s_occluded, StatCounters& st) {
+                            uint32_t lane, const PairLds& L, Hit& hit, bool& c_found, bool& s_occluded, StatCounters& st,
+                            CarryState* cs = nullptr, bool c_resume = false, bool* c_inflight = nullptr) {
     if (!c_want) { c_rd = mk3(0.0f, 0.0f, 1.0f); c_ro = mk3(0.0f, 0.0f, 0.0f); }
     if (!s_want) { s_rd = mk3(0.0f, 0.0f, 1.0f); s_ro = mk3(0.0f, 0.0f, 0.0f); s_tmax = 0.0f; }
     const RaySetup crs = setup_ray(c_rd), srs = setup_ray(s_rd);
     const uint32_t c_kpack = (uint32_t)crs.kx | ((uint32_t)crs.ky << 2) | ((uint32_t)crs.kz << 4);
     const uint32_t s_kpack = (uint32_t)srs.kx | ((uint32_t)srs.ky << 2) | ((uint32_t)srs.kz << 4);
-    L.best[lane] = (0x7f7fffffull << 32) | 0xffffffffull;                 // (FLT_MAX, no triangle)
-    if (lane < 2) L.occl[lane] = 0u;
-    __syncthreads();
+    const bool c_fresh = c_want && !(CARRY > 0 && c_resume);             // a resumed owner's ray is already under way: its key in best[] stays
+    if (c_fresh || !c_want) L.best[lane] = (0x7f7fffffull << 32) | 0xffffffffull;                 // (FLT_MAX, no triangle)
+    if (lane < 2) { L.occl[lane] = 0u; if (CARRY > 0) L.infl[lane] = 0u; }
     const int32_t root = WIDE ? sc.root4 : sc.root;
-    // the ray this lane is WALKING (box tests see distances <= 1e30, see trace_any_deferred); `pend`: its own shadow ray is still to be started
-    f3 w_ro = c_want ? c_ro : s_ro, w_inv = c_want ? crs.inv : srs.inv;
-    float w_t = c_want ? 1e30f : fminf(s_tmax, 1e30f);
-    uint32_t ow = c_want ? lane : (lane | RAY_ANY);
-    bool pend = c_want && s_want;
-    bool done = !c_want && !s_want;
+    // the ray this lane is WALKING (box tests see distances <= 1e30, see trace_any_deferred); `pend`: its own shadow ray is still to be started;
+    // `pend_c` (CARRY): so is its own closest-hit ray, because the lane first walks on with the context it saved in the previous call
+    constexpr bool SFIRST = PT_SHADOW_FIRST != 0;
+    constexpr bool PC = CARRY > 0 || SFIRST;                              // pend_c can be set at all
+    const bool first_c = SFIRST ? (c_fresh && !s_want) : c_fresh;       // the ray the lane starts with is its closest-hit ray
+    f3 w_inv = first_c ? crs.inv : srs.inv, w_ro = walk_origin<WIDE>(first_c ? c_ro : s_ro, w_inv);
+    float w_t = first_c ? 1e30f : fminf(s_tmax, 1e30f);
+    uint32_t ow = first_c ? lane : (lane | RAY_ANY);
+    bool pend = !SFIRST && c_fresh && s_want, pend_c = SFIRST && c_fresh && s_want;
+    bool done = !c_fresh && !s_want;
     int sp = 0, sb = 0;
     int32_t cur = root;
     uint32_t leaf_off = 0;
     uint32_t head = 0, tail = 0;
-    if (STATS) { if (c_want) st.closest_rays++; if (s_want) st.shadow_rays++; }
+    bool allow_carry = false, carry_exit = false;
+    if constexpr (CARRY > 0) {
+        allow_carry = __popcll(__ballot(c_fresh)) >= PT_CARRY_MIN_FRESH;
+        const unsigned long long m_ctx = cs->walk;
+        if (m_ctx != 0ull) {
+            if ((m_ctx >> lane) & 1ull) {
+                const uint32_t* c = L.ring + rank_below(m_ctx) * CTX_DWORDS;
+                const uint32_t pk = c[1];
+                cur = (int32_t)c[0]; sp = (int)(pk & 255u); sb = (int)((pk >> 8) & 255u); leaf_off = pk >> 16;
+                w_ro = mk3(__uint_as_float(c[2]), __uint_as_float(c[3]), __uint_as_float(c[4]));
+                w_inv = mk3(__uint_as_float(c[5]), __uint_as_float(c[6]), __uint_as_float(c[7]));
+                w_t = __uint_as_float(c[8]); ow = c[9];
+                pend_c = c_fresh; pend = s_want; done = false;
+            }
+            cs->walk = 0ull;
+        }
+    }
+    __syncthreads();
+    if (STATS) { if (c_fresh) st.closest_rays++; if (s_want) st.shadow_rays++; }
 
     auto flush = [&](uint32_t n) {            // test ring entries [head, head + n), n <= 64
         PT_PRIO_FLUSH_ENTER;
@@ -1098,18 +1191,27 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
             __syncthreads();
             while (tail - head >= 64u) flush(64u);
         }
-        // a lane that ran dry starts its own pending shadow ray
+        // a lane that ran dry starts its own pending ray (CARRY: the closest-hit ray it has not started yet, then the shadow ray)
+        if (PC && done && pend_c && !(SFIRST && pend)) {
+            pend_c = false; done = false;
+            w_ro = walk_origin<WIDE>(c_ro, crs.inv); w_inv = crs.inv; w_t = 1e30f; ow = lane;
+            cur = root; sp = sb = 0; leaf_off = 0u;
+        } else
         if (done && pend) {
             pend = false; done = false;
-            w_ro = s_ro; w_inv = srs.inv; w_t = fminf(s_tmax, 1e30f); ow = lane | RAY_ANY;
+            w_ro = walk_origin<WIDE>(s_ro, srs.inv); w_inv = srs.inv; w_t = fminf(s_tmax, 1e30f); ow = lane | RAY_ANY;
             cur = root; sp = sb = 0; leaf_off = 0u;
         }
         const unsigned long long m_act = __ballot(!done);
         if (m_act == 0ull) break;
+        if constexpr (CARRY > 0) {
+            // the tail: few lanes left, every one of them on a closest-hit ray, nothing pending -> leave, the stragglers walk on next call
+            if (allow_carry && __popcll(m_act) <= CARRY && !__any((!done && (ow & RAY_ANY) != 0u) || pend || pend_c)) { carry_exit = true; break; }
+        }
         // work stealing: idle lanes take, from lanes that still have something to give, either the PENDING shadow ray as a whole or the
         // bottom stack entry (the largest pending subtree) together with the working ray it belongs to
         if (__popcll(m_act) <= PT_STEAL_MAX_ACTIVE) {
-            const bool donor = !done && (pend || sp > sb);
+            const bool donor = !done && (pend || (PC && pend_c) || sp > sb);
             const unsigned long long m_donor = __ballot(donor);
             if (m_donor != 0ull) {
                 if (STATS && lane == 0) st.w[7]++;       // steal rounds (mi355pt_stats.wave_steps[7])
@@ -1121,10 +1223,12 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
                 const bool taker = done && rank < n_pairs;
                 const uint32_t from = taker ? L.pair[rank] : lane;
                 // what this lane would give: its pending shadow ray from the root, else the bottom of its stack with its working ray
-                const bool give_ray = pend;
-                const f3 g_ro = give_ray ? s_ro : w_ro, g_inv = give_ray ? srs.inv : w_inv;
-                const float g_t = give_ray ? fminf(s_tmax, 1e30f) : w_t;
-                const uint32_t g_ow = give_ray ? (lane | RAY_ANY) : ow;
+                const bool give_c = PC && pend_c && !(SFIRST && pend);   // the own closest-hit ray not yet started (walking a carried context, or the shadow ray first)
+                const bool give_ray = pend || give_c;
+                const f3 g_inv = give_c ? crs.inv : (give_ray ? srs.inv : w_inv);
+                const f3 g_ro = give_ray ? walk_origin<WIDE>(give_c ? c_ro : s_ro, g_inv) : w_ro;
+                const float g_t = give_c ? 1e30f : (give_ray ? fminf(s_tmax, 1e30f) : w_t);
+                const uint32_t g_ow = give_c ? lane : (give_ray ? (lane | RAY_ANY) : ow);
                 const int g_sb = give_ray ? -1 : sb;
                 const int d_sb = __shfl(g_sb, from);
                 const float rx = __shfl(g_ro.x, from), ry = __shfl(g_ro.y, from), rz = __shfl(g_ro.z, from);
@@ -1136,16 +1240,35 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
                     w_ro = mk3(rx, ry, rz); w_inv = mk3(ix, iy, iz); w_t = tb; ow = gow;
                     sp = sb = 0; leaf_off = 0u; done = false;
                 }
-                if (donor && rank < n_pairs) { if (give_ray) pend = false; else ++sb; }
+                if (donor && rank < n_pairs) { if (give_c) pend_c = false; else if (give_ray) pend = false; else ++sb; }
                 __syncthreads();
             }
         }
     }
     if (tail != head) flush(tail - head);     // stragglers' last pairs (tail - head < 64 here)
+    bool inflight = false;
+    if constexpr (CARRY > 0) {
+        if (carry_exit) {
+            // save the walkers' contexts (the ring is empty now) and mark the owners of the rays they are on
+            const unsigned long long m_walk = __ballot(!done);
+            cs->walk = m_walk;
+            if (!done) {
+                uint32_t* c = L.ring + rank_below(m_walk) * CTX_DWORDS;
+                c[0] = (uint32_t)cur; c[1] = (uint32_t)sp | ((uint32_t)sb << 8) | (leaf_off << 16);
+                c[2] = __float_as_uint(w_ro.x); c[3] = __float_as_uint(w_ro.y); c[4] = __float_as_uint(w_ro.z);
+                c[5] = __float_as_uint(w_inv.x); c[6] = __float_as_uint(w_inv.y); c[7] = __float_as_uint(w_inv.z);
+                c[8] = __float_as_uint(w_t); c[9] = ow;
+                atomicOr(&L.infl[(ow & 63u) >> 5], 1u << (ow & 31u));
+            }
+            __syncthreads();
+            inflight = c_want && (((L.infl[lane >> 5] >> (lane & 31u)) & 1u) != 0u);
+        }
+        *c_inflight = inflight;
+    }
     s_occluded = s_want && (((L.occl[lane >> 5] >> (lane & 31u)) & 1u) != 0u);
     const unsigned long long key = L.best[lane];
     const uint32_t tri = (uint32_t)key;
-    c_found = c_want && tri != 0xffffffffu;
+    c_found = c_want && !inflight && tri != 0xffffffffu;
     if (c_found) {                                                           // the winner's barycentrics: same function, same inputs
         TriVerts tv = load_tri(sc.tris, tri);
         float t, b0, b1, b2;

@@ -94,6 +94,12 @@ template <uint32_t FEAT, uint32_t MODE> constexpr bool merged_traversal() {
 #ifndef PT_CLOSEST_COOP
 #define PT_CLOSEST_COOP 1      // needs PT_ANY_DEFERRED (shares its LDS ring)
 #endif
+// Straggler carry-over of the merged traversal (trace_pair_coop, pt_device.hpp): the traversal returns when at most this many lanes are still
+// walking; the owners of the unfinished rays sit out one shading stage and their rays walk on beside the next iteration's.  0: off.
+#ifndef PT_CARRY_MAX
+#define PT_CARRY_MAX 0
+#endif
+template <uint32_t FEAT, uint32_t MODE> constexpr int carry_max() { return PT_CARRY_MAX; }
 // MODE compiles the renderer strategy and the sampler in (MODE_GENERIC reads them from DevParams): the branches on
 // prm.strategy / the sampler mode fold away, worth +2.5 % on C2 (MIS + Sobol), +1.3 % on C5 (NEE + Sobol).
 // Which tree the cooperative traversals walk (both are on the device; the plain traversals of the probes and of the canonical-count
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
 #if PT_CLOSEST_COOP
     __shared__ unsigned long long s_best[64];
     const ClosestLds closest_lds{s_ring, s_best, s_pair};
-    const PairLds pair_lds{s_ring, s_best, s_occl, s_pair};
+    __shared__ uint32_t s_infl[2];
+    const PairLds pair_lds{s_ring, s_best, s_occl, s_pair, s_infl};
 #endif
 #endif
     DevParams prm = prm_in;
@@ -214,7 +221,13 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         park(P);
         bool active = false;
         constexpr bool MERGED = merged_traversal<FEAT, MODE>();
+        constexpr int CARRY = MERGED ? carry_max<FEAT, MODE>() : 0;
         ShadowReq sh{};                                            // merged form: the light connection of the vertex just shaded, traced together with the NEXT closest-hit ray
+        // merged form: a path that ended with a light connection pending stays for one more iteration (`dying`) in which only the connection
+        // is traced, instead of a separate any-hit traversal at the end of the iteration (rare; keeps one traversal instance in the kernel);
+        // `susp` (carry-over): this lane's closest-hit ray is still in flight, the lane sits out the shading stage
+        bool dying = false, susp = false;
+        CarryState carry{0ull};
         while (true) {
             unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
             uint32_t bsdf_classes = 0u;
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 bool occluded = false;
                 if (STATS && sh.on) st.w[6]++;
                 PT_PRIO_TRAV_ENTER;
-                trace_pair_coop<STATS, wide_bvh<FEAT>()>(sc, P.ro, P.rd, active, sh.o, sh.d, sh.t, sh.on, stack, lane, pair_lds, hit, got, occluded, st);
+                trace_pair_coop<STATS, wide_bvh<FEAT>(), CARRY>(sc, P.ro, P.rd, active && !dying, sh.o, sh.d, sh.t, sh.on, stack, lane, pair_lds, hit, got, occluded, st, &carry, susp, &susp);
                 PT_PRIO_TRAV_EXIT;
                 if (sh.on && !occluded) {
 #pragma unroll
@@ -263,20 +276,21 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 bsdf_classes = classes - (__ballot(mclass == MT_EMISSIVE) != 0ull ? 1u : 0u);
                 ts2 = __builtin_amdgcn_s_memtime();
             }
-            bool end_path = false;
+            bool end_path = MERGED && dying;           // a dying path's last connection has just been resolved
             if constexpr (!MERGED) sh = ShadowReq{};
+            const bool shade_now = active && !(MERGED && (dying || susp));
             unpark(P);
             if constexpr ((FEAT & FEAT_CC) != 0u) {
                 ShadeCtx C;
                 C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
-                if (active) end_path = shade_vertex_head<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, C);
+                if (shade_now) end_path = shade_vertex_head<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, C);
                 // the coat's 64-sample directional albedo, estimated by the whole wave for the lanes that need it
-                const bool want_mc = active && C.cont && C.need_cc;
+                const bool want_mc = shade_now && C.cont && C.need_cc;
                 const float fc_mc = coat_directional_albedo_coop(want_mc, C.cc_alpha_c, C.cc_r0c, C.wo_nm, C.mc_key, lane);
                 if (want_mc) C.cc_fc = fc_mc;
-                if (active && C.cont) end_path = shade_vertex_tail<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
+                if (shade_now && C.cont) end_path = shade_vertex_tail<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
             } else {
-                if (active) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
+                if (shade_now) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
             }
             park(P);
             if (STATS) {
@@ -290,10 +304,14 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             // visibility test says: the production path does not trace it (the canonical-count mode does, like the reference)
             if (!canonical && sh.on && sh.c[0] == 0.0f && sh.c[1] == 0.0f && sh.c[2] == 0.0f && sh.c[3] == 0.0f) sh.on = false;
             if (!active) sh.on = false;
-            {
+            if (MERGED && !canonical) {
                 // merged form: the connection of a CONTINUING path waits for the next iteration's traversal; a path that ends here with a
-                // connection pending (a failed BSDF sample after the light was sampled: rare) — and everything in the canonical-count mode — is traced now
-                const bool now = sh.on && (!MERGED || canonical || end_path);
+                // connection pending (a failed BSDF sample after the light was sampled: rare) lives on for that traversal alone
+                dying = sh.on && end_path;
+                if (dying) end_path = false;
+            } else {
+                // two traversals per iteration — and everything in the canonical-count mode: the connection is traced now
+                const bool now = sh.on;
                 if (__any(now)) {
                     if (STATS && now) st.w[6]++;
                     bool occluded = false;
@@ -380,22 +398,36 @@ template <uint32_t MODE>
 void launch_pt_mode(const PtLaunchArgs& a, uint32_t feat) {
     if (pick_features(feat) & FEAT_CC) launch_pt_cc<MODE>(a, feat); else launch_pt_plain<MODE>(a, feat);
 }
-// resident waves per CU of the variant (launch bounds: 4 waves/SIMD, clearcoat variants 3): the persistent grid size
+// resident waves per CU of the EXACT instantiation a launch takes (launch bounds: 4 waves/SIMD, clearcoat variants 3; the register count and
+// so the occupancy can differ between the MODE specialisations, which live in different translation units with their own backend flags):
+// the persistent grid size.  Each translation unit answers for the kernels it holds.
+#define PT_OCC_CASE(F) case (F): e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, (F), MODE>, 64, 0); break;
 template <uint32_t MODE>
-int occupancy_pt_mode(uint32_t feat) {
+int occupancy_pt_plain(uint32_t feat) {
     int per_cu = 0;
     hipError_t e = hipErrorUnknown;
-    switch (pick_features(feat)) {
-#define PT_CASE(F) case (F): e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<false, (F), MODE>, 64, 0); break;
-        PT_FOR_EACH_FEATURE_SET(PT_CASE)
-#undef PT_CASE
-    }
+    switch (pick_features(feat)) { PT_FOR_EACH_PLAIN_SET(PT_OCC_CASE) default: break; }
     return (e == hipSuccess && per_cu > 0) ? per_cu : 8;
 }
+template <uint32_t MODE>
+int occupancy_pt_cc(uint32_t feat) {
+    int per_cu = 0;
+    hipError_t e = hipErrorUnknown;
+    switch (pick_features(feat)) { PT_FOR_EACH_CC_SET(PT_OCC_CASE) default: break; }
+    return (e == hipSuccess && per_cu > 0) ? per_cu : 8;
+}
+#undef PT_OCC_CASE
+template <uint32_t MODE>
+int occupancy_pt_mode(uint32_t feat) { return (pick_features(feat) & FEAT_CC) ? occupancy_pt_cc<MODE>(feat) : occupancy_pt_plain<MODE>(feat); }
 void launch_pt_mis_sobol(const PtLaunchArgs& a, uint32_t feat);      // pt_kernels_mis.hip (plain sets; forwards the clearcoat sets)
 void launch_pt_mis_sobol_cc(const PtLaunchArgs& a, uint32_t feat);   // pt_kernels_mis_cc.hip
 void launch_pt_nee_sobol(const PtLaunchArgs& a, uint32_t feat);      // pt_kernels_nee.hip
 void launch_pt_nee_sobol_cc(const PtLaunchArgs& a, uint32_t feat);   // pt_kernels_nee_cc.hip
 void launch_pt_strategy_pt(const PtLaunchArgs& a, uint32_t feat);    // pt_kernels_pt.hip (the plain path tracer, either sampler)
+int occupancy_pt_mis_sobol(uint32_t feat);
+int occupancy_pt_mis_sobol_cc(uint32_t feat);
+int occupancy_pt_nee_sobol(uint32_t feat);
+int occupancy_pt_nee_sobol_cc(uint32_t feat);
+int occupancy_pt_strategy_pt(uint32_t feat);
 
 }  // namespace pt

@@ -201,15 +201,24 @@ hipError_t launch_probe_occluded(const DevScene& sc, const float* o, const float
 
 namespace pt {
 uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed) { return murmur_dim_seed(dimension, seed); }
-// resident 64-thread blocks (= waves) of the render kernel on the current device: the persistent grid size
-// resident 64-thread blocks of the kernel specialisation that `feat` selects (the clearcoat kernels run 3 waves per SIMD, the
-// others 4): the persistent grid size
-int query_resident_waves(uint32_t feat) {
-    // (the MODE specialisations have the launch bounds of the generic variant of the same feature set)
+// resident 64-thread blocks (= waves) on the current device of the EXACT kernel instantiation launch_pt takes for (stats, feat, sampler,
+// strategy): the persistent grid size.  The MODE specialisations are separate translation units with their own backend flags, so their
+// register counts — and with them the occupancy — need not be those of the generic variant.  Cached per scene and device (api.cpp LaunchCtx).
+int query_resident_waves(bool stats, uint32_t feat, uint32_t sampler, uint32_t strategy) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 2048;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    return prop.multiProcessorCount * occupancy_pt_mode<MODE_GENERIC>(feat);
+    int per_cu = 0;
+    if (stats) {
+        hipError_t e;
+        if ((feat & (FEAT_CC | FEAT_EMTEX)) == 0u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<true, FEAT_STD & ~FEAT_CC, MODE_GENERIC>, 64, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_kernel<true, FEAT_ALL, MODE_GENERIC>, 64, 0);
+        if (e != hipSuccess || per_cu <= 0) per_cu = 8;
+    } else if (sampler == 1u && strategy == 2u) per_cu = occupancy_pt_mis_sobol(feat);
+    else if (sampler == 1u && strategy == 1u) per_cu = occupancy_pt_nee_sobol(feat);
+    else if (strategy == 0u) per_cu = occupancy_pt_strategy_pt(feat);
+    else per_cu = occupancy_pt_mode<MODE_GENERIC>(feat);
+    return prop.multiProcessorCount * per_cu;
 }
 }  // namespace pt

@@ -5,4 +5,5 @@ namespace pt {
 void launch_pt_nee_sobol(const PtLaunchArgs& a, uint32_t feat) {
     if (pick_features(feat) & FEAT_CC) launch_pt_nee_sobol_cc(a, feat); else launch_pt_plain<MODE_NEE_SOBOL>(a, feat);
 }
+int occupancy_pt_nee_sobol(uint32_t feat) { return (pick_features(feat) & FEAT_CC) ? occupancy_pt_nee_sobol_cc(feat) : occupancy_pt_plain<MODE_NEE_SOBOL>(feat); }
 }  // namespace pt

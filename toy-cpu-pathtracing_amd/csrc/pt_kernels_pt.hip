@@ -3,4 +3,5 @@
 #include "pt_kernel.hpp"
 namespace pt {
 void launch_pt_strategy_pt(const PtLaunchArgs& a, uint32_t feat) { launch_pt_mode<MODE_PT>(a, feat); }
+int occupancy_pt_strategy_pt(uint32_t feat) { return occupancy_pt_mode<MODE_PT>(feat); }
 }  // namespace pt

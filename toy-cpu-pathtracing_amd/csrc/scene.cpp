@@ -456,6 +456,18 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         if (!collapse_bvh4(bvh.nodes, bvh.root, tris.size(), &nodes4, &dev.root4, &max_stack, err)) return MI355PT_E_INVALID;
         collapse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc).count();
         dev.n_nodes4 = (uint32_t)nodes4.size();
+#if PT_NODE_FMA
+        {   // pad the boxes the fma slab test sees (layout.hpp PT_NODE_FMA); unused slots (point boxes at FLT_MAX) stay as they are
+            float r = 0.0f;
+            auto used = [](const DevNode4& n, int c) { return n.lox[c] <= n.hix[c] && n.lox[c] < FLT_MAX; };
+            for (const DevNode4& n : nodes4) for (int c = 0; c < 4; ++c) if (used(n, c))
+                for (float v : {n.lox[c], n.loy[c], n.loz[c], n.hix[c], n.hiy[c], n.hiz[c]}) r = std::max(r, std::fabs(v));
+            const float pad = r * NODE4_PAD_REL;
+            for (DevNode4& n : nodes4) for (int c = 0; c < 4; ++c) if (used(n, c)) {
+                n.lox[c] -= pad; n.loy[c] -= pad; n.loz[c] -= pad; n.hix[c] += pad; n.hiy[c] += pad; n.hiz[c] += pad;
+            }
+        }
+#endif
         if ((rc = upload(this, nodes4, &dev.nodes4, err))) return rc;
         bvh4_nodes = nodes4.size();
     }
