@@ -248,6 +248,11 @@ int mi355pt_scene_export_bvh(const mi355pt_scene* s, void* out_nodes, uint32_t* 
  * out_info[4] = {BVH2 nodes, BVH4 nodes, BVH2 depth, worst-case stack entries of the BVH4 (< 24 by construction)}. */
 int mi355pt_probe_bvh_collapse(const float* tri_pos, uint32_t n_tris, const float* rays_od, uint32_t n_rays, uint32_t* out_info,
                                uint32_t* out_mismatch);
+/* The same collapse + validation on a caller-supplied BVH2 (n_nodes 64-byte records in the layout mi355pt_scene_export_bvh writes; leaves
+ * are links < 0 holding first << 3 | count - 1): the guard SceneImpl::build runs before any tree reaches the device, reachable without a
+ * device.  out_info = {nodes2, nodes4, 1 if the cost-optimal collapse ran (0: greedy), worst-case per-lane stack entries}; a tree the
+ * 24-entry LDS stack cannot serve (too deep, broken links, triangles lost) is refused with MI355PT_E_INVALID.  Host only. */
+int mi355pt_probe_bvh_collapse_nodes(const void* bvh2_nodes, uint32_t n_nodes, int32_t root, uint32_t n_tris, uint32_t* out_info /* 4 */);
 /* ZSobolSampler: for each query (x, y, sample_index) emit n_dims raw 32-bit Sobol outputs following the draw
  * pattern string `pattern` of '1' (get_1d) and '2' (get_2d) characters.  z_sobol_sampler.rs:198-230 */
 int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t seed, const uint32_t* xys /* n*3 */,

@@ -41,6 +41,9 @@ def test_gpu_built_tree_finds_the_same_hits(product, pkg, scene_id):
     ih, ig = _info(product, pair["host"][0]), _info(product, pair["gpu"][0])
     assert ih["builder"] == "host" and ig["builder"] == "gpu"
     assert ih["tris"] == ig["tris"] and int(ig["depth"]) <= 22
+    for i in (ih, ig):                                               # worst-case per-lane stack entries of the collapsed tree, validated at build
+        need, cap = map(int, i["stack_need"].split("/"))
+        assert need < cap == 24, i
     assert 0.4 * int(ih["nodes"]) <= int(ig["nodes"]) <= int(ig["tris"])
     o, d = _rays(200000, scene_id)
     th, inst_h, tri_h, nh = pair["host"][0].probe_intersect(o, d)
@@ -127,6 +130,13 @@ def test_large_mesh_gpu_build(product, pkg, n_lon, n_bands, coincident):
     sg, _ = _blob_scene(product, pkg, "gpu" if coincident else "auto", n_lon, n_bands, coincident)
     ih, ig = _info(product, sh), _info(product, sg)
     assert ig["builder"] == "gpu" and int(ig["depth"]) <= 22 and ih["tris"] == ig["tris"]
+    # the stack guard on the tree the GPU builder made (the shape behind the one abort of round 2, tests/test_abi.py): what the build
+    # validated and recorded, and the same check re-run on the exported BVH2
+    need, cap = map(int, ig["stack_need"].split("/"))
+    assert cap == 24 and need < cap, ig
+    nodes, tris, root = product.export_bvh(sg)
+    again = product.probe_bvh_collapse_nodes(nodes, root, tris.shape[0])
+    assert again["max_stack4"] == need and again["nodes4"] == int(ig["nodes4"]), (again, ig)
     if not coincident:
         assert float(ig["bvh_ms"]) < float(ih["bvh_ms"])
     o, d = _rays(100000, 11)

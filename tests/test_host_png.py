@@ -176,3 +176,66 @@ def test_exr_reader_refuses_what_it_does_not_decode(tmp_path):
     open(src, "wb").write(bytes(data))
     r = subprocess.run([EXR_TOOL, src, str(tmp_path / "o.pfm")], capture_output=True, text=True)
     assert r.returncode == 1 and "not supported" in r.stderr
+
+
+EXR_ASAN = EXR_TOOL + "_asan"
+
+
+def _run_asan(src, out):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=99", UBSAN_OPTIONS="halt_on_error=1:exitcode=98")
+    return subprocess.run([EXR_ASAN, src, out], capture_output=True, text=True, env=env, timeout=60)
+
+
+def test_exr_reader_rejects_truncated_and_corrupt_headers_under_asan(tmp_path):
+    """The reader trusts nothing in the header: every truncation of a valid file and a set of targeted corruptions — a channel
+    list without its terminator, zero-sized compression / lineOrder / dataWindow attributes, an inverted, an overflowing and an absurdly
+    large data window, a NONE chunk whose size field lies — must end in the reader's own error (exit code 1), never in a sanitizer report
+    (AddressSanitizer + UBSan build of the same tool, CPU only) and never in a multi-gigabyte allocation."""
+    subprocess.check_call(["make", "-C", os.path.dirname(EXR_TOOL), "exr2pfm_asan"], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(5)
+    w, h = 9, 5
+    rgb = rng.random((h, w, 3)).astype(np.float16)
+    chans = {"R": rgb[..., 0].copy(), "G": rgb[..., 1].copy(), "B": rgb[..., 2].copy()}
+    good = str(tmp_path / "good.exr")
+    _write_exr(good, chans, w, h, 0)
+    blob = open(good, "rb").read()
+    out = str(tmp_path / "o.pfm")
+    r = _run_asan(good, out)
+    assert r.returncode == 0, r.stderr
+
+    def check(data, what):
+        p = str(tmp_path / "bad.exr")
+        open(p, "wb").write(bytes(data))
+        r = _run_asan(p, out)
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (what, r.stderr[-2000:])
+        assert r.returncode == 1, (what, r.returncode, r.stderr[-500:])
+
+    for n in list(range(0, 420, 1)) + [len(blob) - 1, len(blob) - 40]:      # every truncation through the header, and inside the pixel data
+        if n < len(blob):
+            check(blob[:n], f"truncated at {n}")
+
+    def at(name, typ):       # offset of the attribute's size field
+        key = name.encode() + b"\0" + typ.encode() + b"\0"
+        return blob.index(key) + len(key)
+
+    i = at("channels", "chlist")
+    size = struct.unpack_from("<i", blob, i)[0]
+    d = bytearray(blob); d[i + 4 + size - 1] = ord("Z")                        # the list's terminating NUL becomes a name byte
+    check(d, "channel list without terminator")
+    d = bytearray(blob); d[i + 4:i + 4 + size] = b"R" * size                   # one endless name
+    check(d, "endless channel name")
+    for name, typ, payload in (("compression", "compression", 1), ("lineOrder", "lineOrder", 1), ("dataWindow", "box2i", 16)):
+        i = at(name, typ)
+        d = bytearray(blob)
+        d[i:i + 4 + payload] = struct.pack("<i", 0)                            # size 0, payload removed
+        check(d, f"zero-sized {name}")
+    i = at("dataWindow", "box2i") + 4
+    for box, what in (((5, 0, 2, 4), "xMax < xMin"), ((0, 3, 8, 1), "yMax < yMin"), ((-2147483648, 0, 2147483647, 4), "overflowing width"),
+                      ((0, 0, 60000, 60000), "3.6 G pixels"), ((0, 0, 70000, 4), "too wide")):
+        d = bytearray(blob); d[i:i + 16] = struct.pack("<4i", *box)
+        check(d, what)
+    j = blob.index(struct.pack("<ii", 0, w * 3 * 2))                           # first chunk: y = 0, size = one line of three HALF channels
+    d = bytearray(blob); d[j + 4:j + 8] = struct.pack("<i", w * 3 * 2 - 6)     # NONE chunk shorter than a line
+    check(d, "short NONE chunk")
+    d = bytearray(blob); d[j:j + 4] = struct.pack("<i", 77)                    # chunk outside the window
+    check(d, "chunk outside the data window")

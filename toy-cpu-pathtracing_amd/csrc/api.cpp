@@ -716,6 +716,24 @@ int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t 
 // Host-only: sweep-SAH BVH2 over n triangles + the BVH4 collapse, both walked on the CPU for n_rays rays (closest hit over the triangle
 // boxes' entry distances is not the point — the point is that both trees return the SAME set of leaves for every ray, i.e. the collapse
 // loses nothing, and that the collapsed tree's worst-case stack need stays inside STACK_DEPTH).  No device involved.
+int mi355pt_probe_bvh_collapse_nodes(const void* bvh2_nodes, uint32_t n_nodes, int32_t root, uint32_t n_tris, uint32_t* out_info) {
+    if (!bvh2_nodes || !out_info || n_nodes == 0) return fail(MI355PT_E_INVALID, "bad argument");
+    // the same checks SceneImpl::build makes before it uploads a tree: links in range (collapse_bvh4 indexes with them), then the collapse
+    // with its validation of the result (every triangle in one leaf, no cycle, worst-case per-lane stack need < STACK_DEPTH)
+    std::vector<DevNode> n2(n_nodes);
+    std::memcpy(n2.data(), bvh2_nodes, sizeof(DevNode) * n_nodes);
+    if (root >= 0 && (uint32_t)root >= n_nodes) return fail(MI355PT_E_INVALID, "root out of range");
+    for (const DevNode& n : n2) for (int c = 0; c < 2; ++c) if (n.child[c] >= 0 && (uint32_t)n.child[c] >= n_nodes) return fail(MI355PT_E_INVALID, "child link out of range");
+    {   // a cycle or a shared child would make the height computation run forever: every node may be reached once
+        std::vector<uint8_t> seen(n_nodes, 0); std::vector<int32_t> st; if (root >= 0) st.push_back(root);
+        while (!st.empty()) { const int32_t v = st.back(); st.pop_back(); if (seen[(size_t)v]++) return fail(MI355PT_E_INVALID, "BVH2 is not a tree"); for (int c = 0; c < 2; ++c) if (n2[(size_t)v].child[c] >= 0) st.push_back(n2[(size_t)v].child[c]); }
+    }
+    std::vector<DevNode4> n4; int32_t root4 = 0; int max_stack = 0; std::string err; const char* method = "";
+    if (!collapse_bvh4(n2, root, n_tris, &n4, &root4, &max_stack, &err, &method)) return fail(MI355PT_E_INVALID, err);
+    out_info[0] = n_nodes; out_info[1] = (uint32_t)n4.size(); out_info[2] = (uint32_t)(method[0] == 'd' ? 1 : 0); out_info[3] = (uint32_t)max_stack;
+    return MI355PT_OK;
+}
+
 int mi355pt_probe_bvh_collapse(const float* tri_pos, uint32_t n_tris, const float* rays_od, uint32_t n_rays, uint32_t* out_info, uint32_t* out_mismatch) {
     if (!tri_pos || !out_info || n_tris == 0) return fail(MI355PT_E_INVALID, "bad argument");
     std::vector<BuildTri> bt(n_tris);

@@ -294,7 +294,7 @@ struct CollapseDP {
 }  // namespace
 
 bool collapse_bvh4(const std::vector<DevNode>& nodes2, int32_t root2, size_t n_tris, std::vector<DevNode4>* nodes4, int32_t* root4, int* max_stack,
-                   std::string* err) {
+                   std::string* err, const char** method) {
     nodes4->clear();
     nodes4->reserve(nodes2.size() / 2 + 1);
     Collapse4 col{nodes2, *nodes4, std::vector<int>(nodes2.size(), 0)};
@@ -307,12 +307,17 @@ bool collapse_bvh4(const std::vector<DevNode>& nodes2, int32_t root2, size_t n_t
     if (const char* e = getenv("MI355PT_BVH_COLLAPSE")) use_dp = use_dp && std::string(e) != "greedy";
 #endif
     if (use_dp) {
-        CollapseDP dp{nodes2, *nodes4};
-        dp.solve(root2);
-        if (dp.R(root2, STACK_DEPTH - 1) < CollapseDP::INF) *root4 = dp.emit(root2, STACK_DEPTH - 1);
-        else use_dp = false;
+        // the tables take ~504 B per binary node (0.6 GB at the cutoff): a host that cannot spare them gets the greedy collapse, not an
+        // exception through the C ABI
+        try {
+            CollapseDP dp{nodes2, *nodes4};
+            dp.solve(root2);
+            if (dp.R(root2, STACK_DEPTH - 1) < CollapseDP::INF) *root4 = dp.emit(root2, STACK_DEPTH - 1);
+            else use_dp = false;
+        } catch (const std::bad_alloc&) { use_dp = false; }
     }
     if (!use_dp) { nodes4->clear(); *root4 = col.emit(root2, STACK_DEPTH - 1); }
+    if (method) *method = use_dp ? "dp" : "greedy";
     // the guarantees the kernel relies on, checked on the tree that is uploaded: links in range, no cycle, every triangle in exactly one
     // leaf, worst-case pending siblings along any path (= the per-lane LDS stack need) below STACK_DEPTH
     size_t tris_seen = 0, visited = 0;

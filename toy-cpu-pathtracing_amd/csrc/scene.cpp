@@ -453,7 +453,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         std::vector<DevNode4> nodes4;
         int max_stack = 0;
         auto tc = std::chrono::steady_clock::now();
-        if (!collapse_bvh4(bvh.nodes, bvh.root, tris.size(), &nodes4, &dev.root4, &max_stack, err)) return MI355PT_E_INVALID;
+        if (!collapse_bvh4(bvh.nodes, bvh.root, tris.size(), &nodes4, &dev.root4, &max_stack, err, &collapse_method)) return MI355PT_E_INVALID;
+        bvh4_stack_need = max_stack;
         collapse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc).count();
         dev.n_nodes4 = (uint32_t)nodes4.size();
 #if PT_NODE_FMA
@@ -525,8 +526,9 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             m.roughness_tex != 0xffffffffu || m.cc_thickness_tex != 0xffffffffu) features |= FEAT_TEX;
     }
     {
-        char tail[160];
-        std::snprintf(tail, sizeof(tail), " builder=%s bvh_ms=%.2f bvh_device_ms=%.2f collapse_ms=%.2f", bvh_builder_used == MI355PT_BVH_GPU ? "gpu" : "host", bvh_build_ms, bvh_device_ms, collapse_ms);
+        char tail[224];
+        std::snprintf(tail, sizeof(tail), " builder=%s bvh_ms=%.2f bvh_device_ms=%.2f collapse=%s collapse_ms=%.2f stack_need=%d/%d", bvh_builder_used == MI355PT_BVH_GPU ? "gpu" : "host",
+                      bvh_build_ms, bvh_device_ms, collapse_method, collapse_ms, bvh4_stack_need, STACK_DEPTH);
         info = "nodes4=" + std::to_string(bvh4_nodes) + " nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth) + tail;
     }
     built = true;

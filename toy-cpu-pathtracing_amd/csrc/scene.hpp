@@ -29,7 +29,7 @@ struct BvhOut {
 void build_bvh(const std::vector<BuildTri>& tris, BvhOut* out);
 // BVH2 -> BVH4 for the cooperative traversals (layout.hpp DevNode4), with the stack-need guarantee validated; host only (bvh_builder.cpp)
 bool collapse_bvh4(const std::vector<DevNode>& nodes2, int32_t root2, size_t n_tris, std::vector<DevNode4>* nodes4, int32_t* root4, int* max_stack,
-                   std::string* err);
+                   std::string* err, const char** method = nullptr);   // *method: "dp" (cost-optimal) or "greedy" (above 1.2 M nodes, or no memory for the tables)
 // SAH constants shared by both builders (env overrides MI355PT_BVH_COST_TRI / MI355PT_BVH_LEAF are for sweeps only)
 void bvh_build_config(float* cost_traverse, float* cost_tri, int* leaf_max);
 // The same contract built on the current HIP device (bvh_gpu.hip): breadth-first binned SAH, one round of launches
@@ -68,6 +68,8 @@ struct SceneImpl {
     int bvh_builder = 0;          // MI355PT_BVH_AUTO / _HOST / _GPU (mi355pt_scene_set_bvh_builder)
     int bvh_builder_used = 1;     // what build() took
     double collapse_ms = 0.0;     // host time of the 2-wide -> 4-wide collapse
+    const char* collapse_method = "";   // "dp" or "greedy" (scene_info)
+    int bvh4_stack_need = 0;      // worst-case per-lane stack entries the collapsed tree can need (< STACK_DEPTH, validated)
     double bvh_build_ms = 0.0;    // wall time of the BVH build inside build(); bvh_device_ms: device part of a GPU build
     double bvh_device_ms = 0.0;
     uint32_t features = FEAT_ALL;   // FEAT_* bits the scene's materials need (kernel specialisation)

@@ -112,7 +112,7 @@ def _ptr(a, ty):
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
     "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_set_bvh_builder", "scene_build", "render", "render_accum_device", "film_resolve_device",
-    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log", "scene_build_multi", "render_multi", "scene_export_bvh", "coat_albedo_table", "probe_bvh_collapse",
+    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log", "scene_build_multi", "render_multi", "scene_export_bvh", "coat_albedo_table", "probe_bvh_collapse", "probe_bvh_collapse_nodes",
     "last_error", "version",
 ]
 
@@ -366,6 +366,16 @@ class Product(Backend):
         fn.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         self.check(fn(_ptr(tri, C.c_float), tri.shape[0], _ptr(rays, C.c_float), rays.shape[0], _ptr(info, C.c_uint32), C.byref(mism)), "probe_bvh_collapse")
         return dict(nodes2=int(info[0]), nodes4=int(info[1]), depth2=int(info[2]), max_stack4=int(info[3])), mism.value
+
+    def probe_bvh_collapse_nodes(self, nodes, root, n_tris):
+        """mi355pt_probe_bvh_collapse_nodes (host-only): the collapse + validation SceneImpl::build runs, on a caller-supplied BVH2
+        ((n, 16) uint32 view of the 64-B records, as export_bvh returns).  Raises RuntimeError when the tree is refused."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 16)
+        info = np.zeros(4, np.uint32)
+        fn = self.lib.mi355pt_probe_bvh_collapse_nodes
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32)]
+        self.check(fn(nodes.ctypes.data, nodes.shape[0], root, n_tris, _ptr(info, C.c_uint32)), "probe_bvh_collapse_nodes")
+        return dict(nodes2=int(info[0]), nodes4=int(info[1]), dp=bool(info[2]), max_stack4=int(info[3]))
 
     def coat_albedo_table(self, alpha, r0):
         """mi355pt_coat_albedo_table: the 64-entry E(cos theta) table behind params.albedo_lut (host-only)."""

@@ -327,23 +327,33 @@ inline std::vector<float> load_exr(const std::string& path, uint32_t* w_out, uin
         const uint32_t size = rd32();
         need(size);
         const size_t q = p;
+        const size_t q_end = q + size;                  // every read of this attribute stays below q_end (need(size) above: q_end <= d.size())
+        auto attr_need = [&](size_t at, size_t n) { if (at > q_end || n > q_end - at) throw std::runtime_error(path + ": malformed EXR header attribute '" + name + "'"); };
         if (name == "channels") {
             size_t c = q;
-            while (c < q + size && d[c]) {
-                Chan ch; while (d[c]) ch.name.push_back((char)d[c++]); ++c;
-                std::memcpy(&ch.type, &d[c], 4); c += 4 + 4;       // pixel type; pLinear + 3 reserved
+            for (;;) {
+                attr_need(c, 1);
+                if (!d[c]) break;                                           // the list ends with an empty name
+                Chan ch;
+                for (;;) { attr_need(c, 1); const char k = (char)d[c++]; if (!k) break; ch.name.push_back(k); if (ch.name.size() > 255) throw std::runtime_error(path + ": bad EXR channel name"); }
+                attr_need(c, 16);                                           // pixel type; pLinear + 3 reserved; xSampling; ySampling
+                std::memcpy(&ch.type, &d[c], 4); c += 4 + 4;
                 uint32_t xs, ys; std::memcpy(&xs, &d[c], 4); std::memcpy(&ys, &d[c + 4], 4); c += 8;
                 if (xs != 1 || ys != 1) throw std::runtime_error(path + ": sub-sampled EXR channels are not supported");
                 chans.push_back(ch);
+                if (chans.size() > 1024) throw std::runtime_error(path + ": too many EXR channels");
             }
-        } else if (name == "compression") compression = d[q];
-        else if (name == "dataWindow") { std::memcpy(win, &d[q], 16); have_win = true; }
-        else if (name == "lineOrder") line_order = d[q];
-        p = q + size;
+        } else if (name == "compression") { attr_need(q, 1); compression = d[q]; }
+        else if (name == "dataWindow") { attr_need(q, 16); std::memcpy(win, &d[q], 16); have_win = true; }
+        else if (name == "lineOrder") { attr_need(q, 1); line_order = d[q]; }
+        p = q_end;
     }
     if (!have_win || chans.empty() || compression < 0) throw std::runtime_error(path + ": EXR header lacks channels / compression / dataWindow");
     if (compression != 0 && compression != 2 && compression != 3) throw std::runtime_error(path + ": EXR compression " + std::to_string(compression) + " is not supported (NONE, ZIPS, ZIP are)");
-    const uint32_t w = (uint32_t)(win[2] - win[0] + 1), h = (uint32_t)(win[3] - win[1] + 1);
+    // the window in 64-bit arithmetic: xMax < xMin, an overflowing extent or an absurd pixel count is a malformed file, not an allocation
+    const int64_t w64 = (int64_t)win[2] - (int64_t)win[0] + 1, h64 = (int64_t)win[3] - (int64_t)win[1] + 1;
+    if (w64 < 1 || h64 < 1 || w64 > 65536 || h64 > 65536 || w64 * h64 > ((int64_t)1 << 28)) throw std::runtime_error(path + ": EXR data window is empty or too large");
+    const uint32_t w = (uint32_t)w64, h = (uint32_t)h64;
     int idx[3] = {-1, -1, -1};
     size_t line_bytes = 0; std::vector<size_t> chan_off(chans.size());
     for (size_t i = 0; i < chans.size(); ++i) {
@@ -363,9 +373,10 @@ inline std::vector<float> load_exr(const std::string& path, uint32_t* w_out, uin
         const int32_t y0 = (int32_t)rd32(); const uint32_t size = rd32();
         need(size);
         if (y0 < win[1] || y0 > win[3]) throw std::runtime_error(path + ": EXR chunk outside the data window");
-        const uint32_t rows = std::min<uint32_t>(lines_per_block, (uint32_t)(win[3] - y0 + 1));
+        const uint32_t rows = (uint32_t)std::min<int64_t>(lines_per_block, (int64_t)win[3] - (int64_t)y0 + 1);
         const size_t raw_size = line_bytes * rows;
         std::vector<uint8_t> raw;
+        if (compression == 0 && size != raw_size) throw std::runtime_error(path + ": EXR chunk has the wrong size");
         if (compression == 0 || size == raw_size) raw.assign(d.begin() + (long)p, d.begin() + (long)(p + size));
         else {
             std::vector<uint8_t> t = png_detail::inflate(&d[p], size);
