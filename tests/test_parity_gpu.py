@@ -198,9 +198,13 @@ def test_solid_plastic_flips_are_the_roulette_gate(product, oracle, pkg, scene_i
     """Root cause of the round-1 'open divergence' on the solid plastic heroes (scene_9.rs, scene_13.rs): a specular REFLECTION off a
     constant-eta dielectric returns f = F and pdf = F / (F + (1 - F)) (dielectric.rs:380-466), so the throughput becomes
     T * (F * (1 / pdf)) = 1 or 1 - 1 ulp depending on the last bit of F — and apply_russian_roulette (base_renderer.rs:76-92) draws
-    its random number only if max(T) < 1.  The product builds shading frames from cross products and uses the transpose as the inverse,
-    the reference inverts a Mat4 numerically: cos(theta) differs in the last ulp for a share of the vertices, F with it, the gate falls
-    the other way and every later Sobol dimension of that sample shifts (a different but equally valid path).  Proof by intervention:
+    its random number only if max(T) < 1.  cos(theta) differs between product and reference in the last ulp for a share of the vertices,
+    F with it, the gate falls the other way and every later Sobol dimension of that sample shifts (a different but equally valid path).
+    Where the ulp comes from was measured in round 3 (tools/frame_inverse_probe.py, profiles/r03_frame_inverse_probe.jsonl): the product
+    intersects triangles pre-translated to render space where the reference moves each ray into the primitive's local space, and it
+    transposes the shading frame where the reference inverts a Mat4 numerically (pt_path.hpp PT_FRAME_INVERSE builds glam's inverse: by
+    itself 0.286 % -> 0.263 % on scene 9, together with a render-space oracle 0.053 %) — two roundings that compound, and a third source
+    not yet found.  Proof by intervention that the GATE is where the paths part:
     with the gate relaxed to max(T) >= 1 - 1e-5 on BOTH sides (mi355pt_params.rr_gate_slack) the two implementations trace the same
     paths again; with the reference's gate the share of flipped samples is what tools/divergence_probe.py measured (0.29 % / 0.09 %,
     first differing depth spread evenly over the path: profiles/r02_divergence_scene{9,13}.json).  Dispersive glass (scene 8: F differs
@@ -528,7 +532,8 @@ def test_baseline_configs_at_true_size_match_the_oracle(product, oracle, pkg, na
     pair = {}
     for be_name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()
-        pair[be_name] = (sc, pkg.scenes.load_scene(sc, scene_id, w, h, tex_size=256))
+        # C2 with bench.py's own input: the default 1024 x 1024 albedo and normal textures of scene 3 (the other configs have no textures)
+        pair[be_name] = (sc, pkg.scenes.load_scene(sc, scene_id, w, h, tex_size=1024 if name == "C2" else 256))
     oracle.set_faithful(pair["cpu"][0], False)
     prm = pkg.make_params(spp, strategy, "sobol", shard_index=shard_index, shard_count=shard_count)
     L, lam, pdf, film_g = product.render_sample_log(pair["gpu"][0], pair["gpu"][1], prm, 0, spp, want_accum=True)
@@ -559,14 +564,20 @@ def test_baseline_configs_at_true_size_match_the_oracle(product, oracle, pkg, na
     assert close.mean() >= 0.999, close.mean()
 
 
-@pytest.mark.parametrize("device_ids", [[0], [0, 0, 0]])
+@pytest.mark.parametrize("device_ids", [[0], [0, 0, 0], "all", "all_reversed"])
 def test_render_multi_is_render(product, pkg, device_ids):
-    """mi355pt_scene_build_multi + mi355pt_render_multi (one process, the frame's tiles dealt to several devices, peer gather, resolve on
-    the first) return the frame mi355pt_render returns.  On the one-GPU box the device list repeats device 0, which exercises the
-    replicas, the per-device streams and events, the sharding, the staged gather + add and the resolve; with one device the frame is
-    bit-identical, with three shards only the float summation order inside a pixel may move (the launcher may split sample ranges
-    differently for a third of the tiles)."""
+    """mi355pt_scene_build_multi + mi355pt_render_multi (one process, the frame's tiles dealt to several devices, each peer's shard
+    packed to a compact film and pushed to the first device, unpacked there, resolved) return the frame mi355pt_render returns.  On the
+    one-GPU box the device list repeats device 0, which exercises the replicas, the per-device streams and events, the sharding, the
+    pack / peer copy / unpack and the resolve; with one device the frame is bit-identical, with several shards only the float summation
+    order inside a pixel may move (the launcher may split sample ranges differently for a share of the tiles).  "all": every GPU the box
+    has, as real peers over xGMI (skipped with one GPU) — also with the LAST device gathering, so that the first device of the list is
+    not the process's current one and the per-scene launch context has to follow the scene."""
     import torch
+    if isinstance(device_ids, str):
+        if torch.cuda.device_count() < 2:
+            pytest.skip("one GPU: real peers need a multi-GPU box")
+        device_ids = list(range(torch.cuda.device_count()))[::-1 if device_ids == "all_reversed" else 1]
     assert all(d < torch.cuda.device_count() for d in device_ids)
     ref_sc = product.new_scene()
     cam = pkg.scenes.load_scene(ref_sc, 3, 200, 150, tex_size=128)
@@ -673,3 +684,27 @@ def test_regression_runner_rehearsal(product, pkg, tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout and "RMSE 0.000000" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([sys.executable, runner, "--references", str(refs), "--only", "reference_pt_sobol"], capture_output=True, text=True)
     assert r.returncode == 1 and "CHECKSUM" in r.stdout
+
+
+def test_bench_n_gpus_reproduces_the_one_gpu_film_bit_for_bit():
+    """bench.py --gpus 2 (one rank per GPU over RCCL: tiles dealt round-robin, one film reduce) against bench.py --gpus 1 on a small
+    frame: the digest of the reduced film printed in the JSON line (`film_check.sha256`) is the same — disjoint tiles and a deterministic
+    in-wave schedule make the N-GPU film the 1-GPU film, bit for bit.  Needs two GPUs (skipped on the one-GPU box); both runs are child
+    processes, so this process never initialises a second device."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: the RCCL path needs a multi-GPU box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--width", "256", "--height", "200",
+                            "--spp", "64", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1]
+        j = json.loads(line)
+        assert j["n_gpus"] == n and j["film_check"] and j["film_check"]["mean"] > 0.01
+        digests[n] = j["film_check"]["sha256"]
+    assert digests[1] == digests[2], digests

@@ -9,10 +9,10 @@ TAG=$1; shift
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps ${STEPS:-4} --warmup 1 --no-cpu-baseline $@"
 pass() {   # pass <dir> <rocprofv3 options...>
   local d=$1; shift
-  timeout -k 10 400 rocprofv3 "$@" --output-format csv -d $OUT/$d -- python3 $R/bench.py $ARGS > $OUT/$d.log 2>&1 || { echo "pass $d failed"; tail -5 $OUT/$d.log; exit 1; }
+  timeout -k 10 ${PASS_TIMEOUT:-400} rocprofv3 "$@" --output-format csv -d $OUT/$d -- python3 $R/bench.py $ARGS > $OUT/$d.log 2>&1 || { echo "pass $d failed"; tail -5 $OUT/$d.log; exit 1; }
 }
 pass trace --kernel-trace --stats
 pass pmc_fetch --pmc FETCH_SIZE
@@ -20,6 +20,9 @@ pass pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 pass pmc_sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
 pass pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM
 pass pmc_grbm --pmc GRBM_GUI_ACTIVE
+# the vector-memory path (TA = address unit, TCP = L1): one pass per group, each fits one pass on gfx950
+pass pmc_ta --pmc TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum
+pass pmc_tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 python3 - "$OUT" "$ARGS" "$R" <<'PY'
 import csv, glob, sys, collections, json, shutil, re
 out_dir, args, root = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -66,7 +69,7 @@ if "TCC_HIT_sum_per_launch" in traffic:
     traffic["l2_hit_rate"] = h / max(h + m, 1.0)
 json.dump(traffic, open(out_dir + "/pmc_traffic.json", "w"), indent=1)
 valu = {k: res[k] for k in ("command", "kernel", "workload", "samples_per_launch", "library") if k in res}
-valu.update(counters("pmc_sq1")); valu.update(counters("pmc_sq2")); valu.update(counters("pmc_grbm"))
+valu.update(counters("pmc_sq1")); valu.update(counters("pmc_sq2")); valu.update(counters("pmc_grbm")); valu.update(counters("pmc_ta")); valu.update(counters("pmc_tcp"))
 if "SQ_INSTS_VALU_per_launch" in valu and "samples_per_launch" in valu:
     ms = res.get("avg_launch_ms_excluding_warmup", 0.0)
     iv = valu["SQ_INSTS_VALU_per_launch"]
@@ -76,6 +79,13 @@ if "SQ_INSTS_VALU_per_launch" in valu and "samples_per_launch" in valu:
     if ms:
         valu["valu_Ginstr_per_s"] = iv / (ms * 1e-3) / 1e9
         valu["issue_frac_of_1228.8G"] = valu["valu_Ginstr_per_s"] / 1228.8
+    if ms and "GRBM_GUI_ACTIVE_per_launch" in valu:     # summed over the 8 XCDs: the clock the GPU held during the launch
+        valu["gpu_clock_ghz"] = valu["GRBM_GUI_ACTIVE_per_launch"] / 8.0 / (ms * 1e-3) / 1e9
+    if ms and "TCP_TOTAL_CACHE_ACCESSES_sum_per_launch" in valu:
+        cyc = ms * 1e-3 * valu.get("gpu_clock_ghz", 2.4) * 1e9
+        valu["l1_tag_lookups_per_clk_per_cu"] = valu["TCP_TOTAL_CACHE_ACCESSES_sum_per_launch"] / 256.0 / cyc
+        if "TA_TA_BUSY_sum_per_launch" in valu: valu["ta_busy"] = valu["TA_TA_BUSY_sum_per_launch"] / 256.0 / cyc
+        if "SQ_INSTS_VMEM_RD_per_launch" in valu: valu["l1_lookups_per_wave_load"] = valu["TCP_TOTAL_CACHE_ACCESSES_sum_per_launch"] / valu["SQ_INSTS_VMEM_RD_per_launch"]
     wc = valu.get("SQ_WAVE_CYCLES_per_launch")
     if wc:   # SQ_* cycle counters are in quad-cycles (MI355X_MICROARCH.md, cycle constants)
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"):

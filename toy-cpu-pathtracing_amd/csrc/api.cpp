@@ -18,6 +18,8 @@ hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const 
                      const PathOut&);
 hipError_t launch_resolve(const float*, uint32_t, uint32_t, float*, hipStream_t);
 hipError_t launch_film_add(float*, const float*, size_t, hipStream_t);
+hipError_t launch_film_pack(const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float*, hipStream_t);
+hipError_t launch_film_unpack(float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const float*, hipStream_t);
 hipError_t launch_probe_sobol(uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t*, hipStream_t);
 hipError_t launch_probe_intersect(const DevScene&, const float*, const float*, uint32_t, float*, uint32_t*, uint32_t*, float*, hipStream_t);
 hipError_t launch_probe_occluded(const DevScene&, const float*, const float*, const float*, uint32_t, uint8_t*, hipStream_t);
@@ -70,9 +72,10 @@ struct MultiPart {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     float* d_film = nullptr;             // full-frame linear film of this device's tile shard
-    float* d_stage = nullptr;            // part 0 only: staging copy of a peer's film
+    float* d_pack = nullptr;             // parts 1..: the shard's tiles as a compact film (tile-major, 192 floats per tile) — what crosses xGMI
+    float* d_stage = nullptr;            // part 0 only: one landing area per peer for those compact films
     float* d_out = nullptr;              // part 0 only: resolved frame
-    size_t film_floats = 0;
+    size_t film_floats = 0, pack_floats = 0, stage_floats = 0;
 };
 struct mi355pt_scene {
     SceneImpl impl;
@@ -217,7 +220,7 @@ static void free_parts(std::vector<MultiPart>& parts) {
         (void)hipSetDevice(m.device);
         if (m.stream) (void)hipStreamDestroy(m.stream);
         if (m.done) (void)hipEventDestroy(m.done);
-        (void)hipFree(m.d_film); (void)hipFree(m.d_stage); (void)hipFree(m.d_out);
+        (void)hipFree(m.d_film); (void)hipFree(m.d_pack); (void)hipFree(m.d_stage); (void)hipFree(m.d_out);
         if (i > 0) delete m.scene;
     }
     parts.clear();
@@ -622,30 +625,55 @@ int mi355pt_render_multi(const mi355pt_scene* s, const mi355pt_camera* cam, cons
     const size_t film = (size_t)cam->width * cam->height * 3, film_pad = (film + 3) / 4 * 4;
     int rc = MI355PT_OK;
     auto hip_ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == MI355PT_OK) rc = fail(MI355PT_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
-    // 1. every device renders its tile shard into its own zeroed film, concurrently
+    // the shards: device i renders frame tiles i, i + n, i + 2 n, ...; its share of the film is tiles_of(i) * 192 floats
+    const uint32_t tiles_total = ((cam->width + 7u) / 8u) * ((cam->height + 7u) / 8u);
+    auto tiles_of = [&](uint32_t i) { return tiles_total > i ? (tiles_total - i + n - 1u) / n : 0u; };
+    std::vector<size_t> stage_off(n, 0);
+    size_t stage_total = 0;
+    for (uint32_t i = 1; i < n; ++i) { stage_off[i] = stage_total; stage_total += (size_t)tiles_of(i) * 192u; }
+    // 1. every device renders its tile shard into its own zeroed film, concurrently; a peer then packs its tiles and PUSHES the compact
+    //    film (film / n bytes) into its own landing area on the first device, on its own stream: the n - 1 transfers overlap each other
+    //    and the first device's rendering
+    {
+        MultiPart& r = parts[0];
+        if (hip_ok(hipSetDevice(r.device), "hipSetDevice") && r.stage_floats < stage_total) {
+            (void)hipFree(r.d_stage); r.d_stage = nullptr; r.stage_floats = 0;
+            if (hip_ok(hipMalloc((void**)&r.d_stage, stage_total * sizeof(float)), "hipMalloc stage")) r.stage_floats = stage_total;
+        }
+    }
     for (uint32_t i = 0; i < n && rc == MI355PT_OK; ++i) {
         MultiPart& m = parts[i];
         if (!hip_ok(hipSetDevice(m.device), "hipSetDevice")) break;
         if (m.film_floats != film_pad) {
-            (void)hipFree(m.d_film); (void)hipFree(m.d_stage); (void)hipFree(m.d_out); m.d_film = m.d_stage = m.d_out = nullptr; m.film_floats = 0;
+            (void)hipFree(m.d_film); (void)hipFree(m.d_out); m.d_film = m.d_out = nullptr; m.film_floats = 0;
             if (!hip_ok(hipMalloc((void**)&m.d_film, film_pad * sizeof(float)), "hipMalloc film")) break;
-            if (i == 0 && n > 1 && !hip_ok(hipMalloc((void**)&m.d_stage, film_pad * sizeof(float)), "hipMalloc stage")) break;
             if (i == 0 && !hip_ok(hipMalloc((void**)&m.d_out, film_pad * sizeof(float)), "hipMalloc out")) break;
             m.film_floats = film_pad;
+        }
+        const size_t pack = (size_t)tiles_of(i) * 192u;
+        if (i > 0 && m.pack_floats < pack) {
+            (void)hipFree(m.d_pack); m.d_pack = nullptr; m.pack_floats = 0;
+            if (!hip_ok(hipMalloc((void**)&m.d_pack, std::max<size_t>(pack, 1) * sizeof(float)), "hipMalloc pack")) break;
+            m.pack_floats = pack;
         }
         if (!hip_ok(hipMemsetAsync(m.d_film, 0, film_pad * sizeof(float), m.stream), "hipMemsetAsync")) break;
         mi355pt_params q = *p;
         q.shard_index = i; q.shard_count = n;
         if ((rc = mi355pt_render_accum_device(m.scene, cam, &q, 0, p->spp, m.d_film, (void*)m.stream, nullptr))) break;
+        if (i > 0 && pack) {
+            if (!hip_ok(launch_film_pack(m.d_film, cam->width, cam->height, i, n, tiles_of(i), m.d_pack, m.stream), "film pack")) break;
+            if (!hip_ok(hipMemcpyPeerAsync(parts[0].d_stage + stage_off[i], parts[0].device, m.d_pack, m.device, pack * sizeof(float), m.stream), "hipMemcpyPeerAsync")) break;
+        }
         hip_ok(hipEventRecord(m.done, m.stream), "hipEventRecord");
     }
-    // 2. gather onto the first device (peer copy over xGMI, then add: disjoint tiles, fixed order), resolve, copy out
+    // 2. on the first device: each landed shard is written into the film (disjoint tiles: stores in a fixed order, exact and
+    //    deterministic), then resolve and copy out
     if (rc == MI355PT_OK && hip_ok(hipSetDevice(parts[0].device), "hipSetDevice")) {
         MultiPart& r = parts[0];
         for (uint32_t i = 1; i < n && rc == MI355PT_OK; ++i) {
+            if (!tiles_of(i)) continue;
             if (!hip_ok(hipStreamWaitEvent(r.stream, parts[i].done, 0), "hipStreamWaitEvent")) break;
-            if (!hip_ok(hipMemcpyPeerAsync(r.d_stage, r.device, parts[i].d_film, parts[i].device, film_pad * sizeof(float), r.stream), "hipMemcpyPeerAsync")) break;
-            hip_ok(launch_film_add(r.d_film, r.d_stage, film_pad, r.stream), "film add");
+            hip_ok(launch_film_unpack(r.d_film, cam->width, cam->height, i, n, tiles_of(i), r.d_stage + stage_off[i], r.stream), "film unpack");
         }
         if (rc == MI355PT_OK) rc = mi355pt_film_resolve_device(r.d_film, cam->width * cam->height, p->spp, r.d_out, (void*)r.stream);
         if (rc == MI355PT_OK) hip_ok(hipMemcpyAsync(out_rgb, r.d_out, film * sizeof(float), hipMemcpyDeviceToHost, r.stream), "hipMemcpyAsync");

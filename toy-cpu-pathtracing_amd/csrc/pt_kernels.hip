@@ -117,6 +117,30 @@ __global__ void film_add_kernel(float* __restrict__ dst, const float* __restrict
     }
 }
 
+// Multi-device gather (mi355pt_render_multi): a device's shard of the frame as a COMPACT film — its 8x8 tiles in shard order (tile k of the
+// shard = frame tile shard_index + k * shard_count), 64 pixels x 3 floats each, pixels outside the frame 0 — so that 1/N of the film
+// crosses xGMI per peer instead of the whole frame; and the inverse on the gathering device (the shards' tiles are disjoint: plain stores).
+__global__ void film_pack_kernel(const float* __restrict__ film, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_index, uint32_t shard_count,
+                                 uint32_t n_tiles, float* __restrict__ packed) {
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    if (k >= n_tiles) return;
+    const uint32_t tile = shard_index + k * shard_count;
+    const uint32_t px = (tile % tiles_x) * 8u + (lane & 7u), py = (tile / tiles_x) * 8u + (lane >> 3);
+    const bool in = px < width && py < height;
+    const size_t o = ((size_t)py * width + px) * 3, q = ((size_t)k * 64u + lane) * 3u;
+    packed[q] = in ? film[o] : 0.0f; packed[q + 1] = in ? film[o + 1] : 0.0f; packed[q + 2] = in ? film[o + 2] : 0.0f;
+}
+__global__ void film_unpack_kernel(float* __restrict__ film, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_index, uint32_t shard_count,
+                                   uint32_t n_tiles, const float* __restrict__ packed) {
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    if (k >= n_tiles) return;
+    const uint32_t tile = shard_index + k * shard_count;
+    const uint32_t px = (tile % tiles_x) * 8u + (lane & 7u), py = (tile / tiles_x) * 8u + (lane >> 3);
+    if (px >= width || py >= height) return;
+    const size_t o = ((size_t)py * width + px) * 3, q = ((size_t)k * 64u + lane) * 3u;
+    film[o] = packed[q]; film[o + 1] = packed[q + 1]; film[o + 2] = packed[q + 2];
+}
+
 // adds the per-chunk film tiles of a split launch to the film, in chunk order (one thread per pixel of each tile of the shard)
 __global__ void combine_kernel(DevCamera cam, DevParams prm, const float* __restrict__ partial, float* __restrict__ accum, uint32_t n_tiles) {
     const uint32_t tile_k = blockIdx.x, lane = threadIdx.x;
@@ -160,6 +184,14 @@ hipError_t launch_film_add(float* dst, const float* src, size_t n_floats, hipStr
     const size_t n4 = n_floats / 4;
     int grid = (int)std::min<size_t>((n4 + 255) / 256, 4096);
     hipLaunchKernelGGL(film_add_kernel, dim3(grid), dim3(256), 0, stream, dst, src, n4);
+    return hipGetLastError();
+}
+hipError_t launch_film_pack(const float* film, uint32_t w, uint32_t h, uint32_t shard_index, uint32_t shard_count, uint32_t n_tiles, float* packed, hipStream_t stream) {
+    if (n_tiles) hipLaunchKernelGGL(film_pack_kernel, dim3(n_tiles), dim3(64), 0, stream, film, w, h, (w + 7u) / 8u, shard_index, shard_count, n_tiles, packed);
+    return hipGetLastError();
+}
+hipError_t launch_film_unpack(float* film, uint32_t w, uint32_t h, uint32_t shard_index, uint32_t shard_count, uint32_t n_tiles, const float* packed, hipStream_t stream) {
+    if (n_tiles) hipLaunchKernelGGL(film_unpack_kernel, dim3(n_tiles), dim3(64), 0, stream, film, w, h, (w + 7u) / 8u, shard_index, shard_count, n_tiles, packed);
     return hipGetLastError();
 }
 hipError_t launch_resolve(const float* d_accum, uint32_t n_values, uint32_t spp, float* d_out, hipStream_t stream) {

@@ -20,6 +20,43 @@ PT_DEV Frame shading_frame(f3 shading_normal, f3 tangent) {
     f.t = normalize(cross(f.b, f.n));
     return f;
 }
+// The reference does not transpose: Transform::from_shading_normal_tangent returns glam's NUMERIC Mat4::inverse of [T B N 0; 0 0 0 1]
+// (math/src/transform.rs:186-203), and the way back (base_renderer.rs:111 `render_to_tangent.inverse()`, Transform * Normal's inverse-
+// transpose, transform.rs:45-51) is the numeric inverse of THAT.  The entries differ from the transpose in the last ulp; where a decision
+// hangs on an ulp — the Russian-roulette gate on T = F * (1 / pdf) = 1 +- ulp after a specular reflection off a constant-eta dielectric,
+// DESIGN.md 2.1 — a path then takes another, equally valid, turn.  PT_FRAME_INVERSE builds both matrices with glam's cofactor arithmetic
+// (o_math.hpp `inverse`, specialised for the zero / one entries of an affine matrix without translation: every dropped term is an exact
+// 0): 1 = in the kernels that hold such materials (FEAT_DIEL), 2 = in every kernel, 0 = transpose (DEFAULT).
+// Measured (round 3, tools/frame_inverse_probe.py, profiles/r03_frame_inverse_probe.jsonl; share of 196 608 samples of a 64x48x64 frame whose
+// radiance leaves the oracle's under the reference's own gate): scene 9 0.286 % -> 0.263 %, scene 13 0.0885 % -> 0.0880 %, scene 19 0.040 % ->
+// 0.042 % — the frames alone explain almost nothing; together with an oracle that intersects pre-translated render-space triangles like the
+// product (Oracle.set_render_space_lowering; alone: 0.216 % / 0.076 % / 0.045 %) 0.053 % / 0.018 % / 0.002 %: the two roundings COMPOUND, and
+// a fifth of the flips has yet another source.  Cost: -1.2...-1.3 % on the dielectric kernels (scenes 8 / 9 / 10), -5.7 % on C2's kernel if
+// applied everywhere.  It does not by itself let the solid-plastic frames pass with the reference's gate, so it is not the default.
+#ifndef PT_FRAME_INVERSE
+#define PT_FRAME_INVERSE 0
+#endif
+template <uint32_t FEAT> constexpr bool numeric_frames() { return PT_FRAME_INVERSE == 2 || (PT_FRAME_INVERSE == 1 && (FEAT & FEAT_DIEL) != 0u); }
+// glam Mat4::inverse of the matrix with columns c0, c1, c2 (and w = (0, 0, 0, 1)): the inverse's columns
+PT_DEV void inverse3_glam(f3 c0, f3 c1, f3 c2, f3& r0, f3& r1, f3& r2) {
+    const float m00 = c0.x, m01 = c0.y, m02 = c0.z, m10 = c1.x, m11 = c1.y, m12 = c1.z, m20 = c2.x, m21 = c2.y, m22 = c2.z;
+    const f3 i0 = mk3(m11 * m22 - m12 * m21, m01 * m22 - m02 * m21, m01 * m12 - m02 * m11);
+    const f3 i1 = mk3(m10 * m22 - m12 * m20, m00 * m22 - m02 * m20, m00 * m12 - m02 * m10);
+    const f3 i2 = mk3(m10 * m21 - m11 * m20, m00 * m21 - m01 * m20, m00 * m11 - m01 * m10);
+    const f3 a0 = mk3(i0.x, -i0.y, i0.z), a1 = mk3(-i1.x, i1.y, -i1.z), a2 = mk3(i2.x, -i2.y, i2.z);
+    const float det = (m00 * a0.x + m01 * a1.x) + m02 * a2.x;
+    const float rcp = 1.0f / det;
+    r0 = a0 * rcp; r1 = a1 * rcp; r2 = a2 * rcp;
+}
+// render -> tangent as the rows to_local() dots with (`fr`), and tangent -> render as the columns to_world() combines (`fw`, also the rows
+// that take a NORMAL to tangent space: inverse-transpose of render -> tangent)
+PT_DEV void shading_frames_numeric(f3 shading_normal, f3 tangent, Frame& fr, Frame& fw) {
+    const Frame o = shading_frame(shading_normal, tangent);               // T, B, N as the reference orthonormalises them
+    f3 r0, r1, r2;
+    inverse3_glam(o.t, o.b, o.n, r0, r1, r2);                              // render -> tangent, columns
+    fr.t = mk3(r0.x, r1.x, r2.x); fr.b = mk3(r0.y, r1.y, r2.y); fr.n = mk3(r0.z, r1.z, r2.z);
+    inverse3_glam(r0, r1, r2, fw.t, fw.b, fw.n);                           // and back
+}
 // Transform::from_normal_map (transform.rs:216-244)
 PT_DEV Frame normal_map_frame(f3 nm) {
     Frame f;
@@ -239,7 +276,7 @@ PT_DEV void regen_path(Path& P, const SamplerCtx& sctx, const DevCamera& cam, ui
 // What the first half hands to the second half:
 struct ShadeCtx {
     Surface sf; const DevMaterial* mat; uint32_t mtype;
-    Frame fr, nf; f3 wo, wo_nm, ng_t; float geo_wo, uc; f2 uv;
+    Frame fr, fw, nf; f3 wo, wo_nm, ng_t; float geo_wo, uc; f2 uv;   // fr: render -> tangent rows; fw: tangent -> render columns (= fr unless numeric_frames)
     bool is_diel, rough_diel, cont;
     float d_alpha;                 // dielectric roughness at the shading point (constant or FloatTexture)
     // clearcoat inputs / result of the cooperative estimate
@@ -406,10 +443,12 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
         }
         if (!end_path) {
             if (STATS) { st.bounces++; tsa = __builtin_amdgcn_s_memtime(); }
-            Frame fr = shading_frame(sf.ns, sf.tangent);
+            Frame fr, fw;
+            if constexpr (numeric_frames<FEAT>()) shading_frames_numeric(sf.ns, sf.tangent, fr, fw);
+            else { fr = shading_frame(sf.ns, sf.tangent); fw = fr; }
             f3 wo_r = -rd;                                                    // Intersection.wo
             f3 wo = to_local(fr, wo_r);
-            f3 ng_t = normalize(to_local(fr, sf.ng));                         // Transform * Normal renormalises
+            f3 ng_t = normalize(to_local(fw, sf.ng));                         // Transform * Normal: inverse-transpose, then renormalised
             // base_renderer.rs:212-213 draws uc then uv for every material.  A draw whose value the material
             // never reads only has to advance the sampler's dimension (Lambert ignores uc, lambert_material.rs:44;
             // the smooth dielectric ignores uv, dielectric.rs:179-180): the Sobol digit loop is ~30 % of this
@@ -443,7 +482,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             }
             f3 wo_nm = to_local(nf, wo);
             // ---- hand-over to the second half ----
-            C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; C.nf = nf; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
+            C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; C.fw = fw; C.nf = nf; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
             C.geo_wo = dot(ng_t, wo); C.uc = uc; C.uv = uv; C.is_diel = is_diel; C.rough_diel = rough_diel; C.d_alpha = d_alpha; C.cont = true;
             if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) {
                 // SimpleClearcoatPbrMaterial: FloatParameter values at the shading point + the inputs of the coat's directional albedo
@@ -486,7 +525,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
     bool& do_shadow = sh.on; f3& sh_o = sh.o; f3& sh_d = sh.d; float& sh_t = sh.t; float* sh_c = sh.c;
     (void)L; (void)from_camera;
     const Surface& sf = C.sf; const DevMaterial* mat = C.mat; const uint32_t mtype = C.mtype;
-    const Frame& fr = C.fr; const Frame& nf = C.nf; const f3 wo = C.wo, wo_nm = C.wo_nm, ng_t = C.ng_t;
+    const Frame& fr = C.fr; const Frame& fw = C.fw; const Frame& nf = C.nf; const f3 wo = C.wo, wo_nm = C.wo_nm, ng_t = C.ng_t;
     const float uc = C.uc; const f2 uv = C.uv; const bool is_diel = C.is_diel, rough_diel = C.rough_diel;
     {
         {
@@ -992,7 +1031,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                             }
                         }
                     } else {
-                    f3 ln_t = normalize(to_local(fr, ln));
+                    f3 ln_t = normalize(to_local(fw, ln));
                     float g = fabsf(dot(ln_t, -wi_t)) / dist2;
                     float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
                     sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
@@ -1008,7 +1047,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                 end_path = true;                                              // process_bsdf_sampling -> None (:102-104,240-253)
             } else {
                 // spawn the next ray (:106-121)
-                f3 wi_r = to_world(fr, wi_sh);
+                f3 wi_r = to_world(fw, wi_sh);
                 float sg = dot(sf.ng, wi_r) < 0.0f ? -1.0f : 1.0f;
                 f3 org = sf.p + (sg * sf.ng) * RAY_EPS;
                 rd = wi_r; ro = org + rd * RAY_EPS;
