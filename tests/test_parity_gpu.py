@@ -139,6 +139,11 @@ FRAME_LIMITS = {
     12: (8e-3, 80),     # four rough BK7 heroes (3.4e-3 / 25): GGX visible-normal sampling near the rim of the disk, pz = sqrt(1 - px^2 - py^2),
     27: (0.03, 150),    # cancels catastrophically, so a 1-ulp sin/cos difference between device and host libm moves the sampled normal
 }
+# share of 30 000 samples whose spectral radiance agrees with the oracle's to 1e-3 (test_other_scenes_radiance_parity): 0.999 unless the scene
+# belongs to one of the two root-caused classes; the values are the measured rates (profiles/r03_per_sample_rates.jsonl) less a margin
+PER_SAMPLE_MIN = {9: 0.996, 13: 0.998,              # solid constant-eta plastic, the reference's own roulette gate: measured 0.9974 / 0.9991
+                  11: 0.993, 12: 0.997, 27: 0.997}     # rough refraction (GGX normal near the rim of the disk): 0.9952 / 0.9989 / 0.9986
+# (every other scene / strategy pair measures 0.9995 ... 1.0000; round 2's bar was 0.98 for all of them)
 KNIFE_EDGE_SCENES = (9, 13, 19)   # solid constant-eta plastic: compared with the Russian-roulette gate relaxed on both sides (next test)
 
 
@@ -305,7 +310,10 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     same_term = np.all(pg == pc, axis=1)
     assert same_term.mean() >= 0.995
     close = np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)
-    assert close.mean() >= 0.98, close.mean()
+    if os.environ.get("MI355PT_PARITY_LOG"):                              # measurement run behind PER_SAMPLE_MIN (below)
+        with open(os.environ["MI355PT_PARITY_LOG"], "a") as f:
+            f.write(f'{{"scene": {scene_id}, "strategy": "{strategy}", "close": {close.mean():.6f}, "same_term": {same_term.mean():.6f}}}\n')
+    assert close.mean() >= PER_SAMPLE_MIN.get(scene_id, 0.999), close.mean()
     # The reference accumulates NaN samples without complaint (sensor.rs:42 only logs).  Rough SF11 glass under MIS makes
     # some: below 370 nm the eta LUT is 0 -> eta' = 1 (dielectric.rs:144-148), the "refracted" ray is -wo, and whenever
     # dot(wi,wm) + dot(wo,wm) rounds to exactly 0 the sample has f = 0 (spectrum / 0 -> 0), pdf = inf and the MIS weight
