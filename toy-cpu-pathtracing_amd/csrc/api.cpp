@@ -15,7 +15,8 @@
 namespace pt {
 struct PathOut { float* L; float* lam; float* pdf; uint32_t s_base, n_s; };   // per-sample log of a launch (pt_path.hpp)
 hipError_t launch_pt(const DevScene&, const DevCamera&, const DevParams&, const uint64_t*, float*, float*, unsigned*, DevStats*, bool, uint32_t, int, hipStream_t,
-                     const PathOut&);
+                     const PathOut&, float*);
+size_t query_defer_bytes_per_wave();
 hipError_t launch_resolve(const float*, uint32_t, uint32_t, float*, hipStream_t);
 hipError_t launch_film_add(float*, const float*, size_t, hipStream_t);
 hipError_t launch_film_pack(const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float*, hipStream_t);
@@ -53,6 +54,8 @@ struct LaunchCtx {
     bool hash_valid = false;
     unsigned* d_counters = nullptr;   // CTX_RING counters
     DevStats* d_stats = nullptr;      // CTX_RING blocks
+    float* d_defer = nullptr;         // the resident waves' deferral queues (pt_kernel.hpp PT_DEFER: 16 KB per wave), sized for the largest grid seen
+    size_t defer_bytes = 0;
     float* d_partial = nullptr;       // per-chunk film tiles of split launches (tiles * chunks * 64 * 3 floats), grown on demand;
     size_t partial_floats = 0;        // reused by consecutive launches: one stream at a time per scene
     int next = 0;
@@ -60,7 +63,7 @@ struct LaunchCtx {
         // freed with the owning device current (a scene rebuilt on another device drops its context from there)
         int cur = -1;
         const bool swap = device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
-        (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); (void)hipFree(d_partial);
+        (void)hipFree(d_hash); (void)hipFree(d_counters); (void)hipFree(d_stats); (void)hipFree(d_partial); (void)hipFree(d_defer);
         if (swap) (void)hipSetDevice(cur);
     }
 };
@@ -501,7 +504,17 @@ static int render_accum_range(const mi355pt_scene* s, const mi355pt_camera* cam,
             lc->partial_floats = need;
         }
     }
-    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, lc->d_partial, d_counter, d_stats, want_stats, s->impl.features, grid, stream, pout));
+    if (const size_t per_wave = query_defer_bytes_per_wave()) {
+        // (one stream at a time per scene, like d_partial: the queues are empty between launches, so consecutive launches share them)
+        const size_t need = per_wave * (size_t)grid;
+        if (need > lc->defer_bytes) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(lc->d_defer); lc->d_defer = nullptr; lc->defer_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&lc->d_defer, need));
+            lc->defer_bytes = need;
+        }
+    }
+    HIP_TRY(launch_pt(s->impl.dev, dc, dp, lc->d_hash, d_accum, lc->d_partial, d_counter, d_stats, want_stats, s->impl.features, grid, stream, pout, lc->d_defer));
     if (stats) {
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(hipEventSynchronize(e1));

@@ -68,7 +68,8 @@ PT_HD inline uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1; }
 struct alignas(16) DevTri {
     float p0[3]; float p1x;
     float p1yz[2]; float p2xy[2];
-    float p2z; uint32_t pad[3];
+    float p2z; uint32_t pad[3];   // pad[0]: sort class of the triangle's material (MT_* | 8 if it has a spectrum texture) — known with the hit, one dependent fetch before the shading record
+                                  // (the deferral queue sorts on it, pt_kernel.hpp PT_DEFER)
 };
 static_assert(sizeof(DevTri) == 48, "tri must be 48 B");
 

@@ -422,9 +422,10 @@ PT_DEV void eval_spectrum(const DevScene& sc, const DevSpectrum& sp, const Wl& w
 // Geometry: watertight ray/triangle (math/src/ray.rs:44-182) and BVH2 traversal with LDS stacks.
 // ---------------------------------------------------------------------------------------------
 struct TriVerts { f3 p0, p1, p2; };
-PT_DEV TriVerts load_tri(const DevTri* tris, uint32_t i) {
+PT_DEV TriVerts load_tri(const DevTri* tris, uint32_t i, uint32_t* mclass = nullptr) {
     const float4* q = (const float4*)(tris + i);
     float4 a = q[0], b = q[1], c = q[2];
+    if (mclass) *mclass = __float_as_uint(c.y);                       // DevTri::pad[0]: sort class of the triangle's material (layout.hpp)
     return TriVerts{mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x)};
 }
 
@@ -490,7 +491,7 @@ PT_DEV RaySetup setup_ray(f3 rd) {
     return r;
 }
 
-struct Hit { float t, b0, b1, b2; uint32_t tri; };
+struct Hit { float t, b0, b1, b2; uint32_t tri; uint32_t mclass; };   // mclass: the sort class of the triangle's material (DevTri::pad[0]: MT_* | 8 if it has a spectrum texture), filled by trace_pair_coop
 
 // Closest hit (Scene::intersect, scene.rs:80-90).  One flat BVH2; the far child goes to this lane's LDS stack
 // (stack[depth*64 + lane]: consecutive lanes hit consecutive banks, no conflicts); t_best prunes both
@@ -1270,10 +1271,11 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
     const uint32_t tri = (uint32_t)key;
     c_found = c_want && !inflight && tri != 0xffffffffu;
     if (c_found) {                                                           // the winner's barycentrics: same function, same inputs
-        TriVerts tv = load_tri(sc.tris, tri);
+        uint32_t mclass;
+        TriVerts tv = load_tri(sc.tris, tri, &mclass);
         float t, b0, b1, b2;
         intersect_triangle(c_ro, c_rd, crs.kx, crs.ky, crs.kz, crs.sx, crs.sy, crs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
-        hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = tri;
+        hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = tri; hit.mclass = mclass;
         if (STATS) st.closest_hits++;
     }
 }

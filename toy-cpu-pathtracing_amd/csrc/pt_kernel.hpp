@@ -100,6 +100,40 @@ template <uint32_t FEAT, uint32_t MODE> constexpr bool merged_traversal() {
 #define PT_CARRY_MAX 0
 #endif
 template <uint32_t FEAT, uint32_t MODE> constexpr int carry_max() { return PT_CARRY_MAX; }
+// MATERIAL SORT BETWEEN BOUNCES, wave-local (PT_DEFER).  A wave shades all its lanes together, so an iteration in which a few lanes hit
+// the hero pays the hero's whole BSDF branch on top of the room's: measured 19-52 k of ~270-300 k cycles per iteration wherever the scene
+// has a second material class, i.e. in 84-93 % of the iterations for 8-13 % of the lanes.  With PT_DEFER a lane whose closest
+// hit lies on a DEFERRED class (the clearcoat material in the kernels that have it, the dielectrics in theirs) does not shade: it writes its
+// path and the hit to the wave's own queue in global memory (128 B per path, a ring of 128 entries per resident wave; L2-resident) and is
+// FREE — it starts a new camera path at the top of the next iteration like a lane whose path ended, so no lane idles for the sort.  When at
+// least PT_DEFER_MIN paths wait (or the work item has no new paths left), the free lanes of the next iteration take queued paths instead of new
+// ones and the wave shades them together: the minority branch runs once for ~30 lanes instead of in every iteration for ~6.  A path only
+// ever waits in the queue of the wave that owns its pixel's LDS film tile, the order of pushes and pops is a function of the wave's own
+// deterministic schedule, and a sample's arithmetic does not depend on when it is shaded: frames stay bit-identical from run to run and
+// sample-for-sample equal to the oracle's.  (Moving paths BETWEEN waves — the usual wavefront formulation — needs 9 KB of LDS per queue or
+// float atomics on the film; sorting inside the wave's own time line needs neither.)
+#ifndef PT_DEFER
+#define PT_DEFER 2             // 0: off; 1: queued paths are taken at the top of an iteration (they sit out its traversal: +4 % scene 17, -5...-9 % dielectrics);
+#endif                         // 2: taken after the shading stage and shaded at once in a second pass (+11...+34 %, dielectrics +-0)
+#ifndef PT_DEFER_MIN
+#define PT_DEFER_MIN 56         // paths waiting before the queue is shaded (20 / 28 / 40 / 48 / 60 measured: scene 17 1 497 / 1 512 / 1 523 / 1 528 / 1 529)
+#endif
+constexpr uint32_t DEFER_RING = 128u;           // entries per wave: a drain starts at PT_DEFER_MIN waiting paths and one iteration adds at most 64
+constexpr uint32_t DEFER_F4 = 8u;               // float4 per entry
+#ifndef PT_DEFER_TEX
+#define PT_DEFER_TEX 1      // textured materials are a class of their own in the kernels without the clearcoat code
+#endif
+template <uint32_t FEAT, uint32_t MODE> constexpr uint32_t defer_classes() {    // bit c: sort class c (MT_* | 8 if the material has a spectrum texture, DevTri::pad[0]) is deferred
+    if (PT_DEFER == 0 || !merged_traversal<FEAT, MODE>()) return 0u;
+    // the clearcoat material wherever it exists (its branch is the longest: +12 % scene 17, +22 % scene 19, +34 % scene 15); in the kernels
+    // without it, the materials with a spectrum texture (bilinear fetches + rgb2spec cells; C2's hero: +0.6 %, scene 4 +0.8 %; a class for
+    // every textured material lost 4 % on the normal-map-only hero of scene 5).  The dielectrics alone measured +-0 (their branch is short)
+    // and are not deferred.
+    if ((FEAT & FEAT_CC) != 0u) return (1u << MT_CLEARCOAT) | (1u << (MT_CLEARCOAT | 8u));
+    if (PT_DEFER_TEX != 0 && (FEAT & FEAT_TEX) != 0u) return 0xff00u;
+    return 0u;
+}
+constexpr size_t defer_bytes_per_wave() { return PT_DEFER ? (size_t)DEFER_RING * DEFER_F4 * 16u : 0u; }
 // MODE compiles the renderer strategy and the sampler in (MODE_GENERIC reads them from DevParams): the branches on
 // prm.strategy / the sampler mode fold away, worth +2.5 % on C2 (MIS + Sobol), +1.3 % on C5 (NEE + Sobol).
 // Which tree the cooperative traversals walk (both are on the device; the plain traversals of the probes and of the canonical-count
@@ -114,7 +148,7 @@ template <uint32_t FEAT> constexpr bool wide_bvh() { return PT_WIDE_BVH != 0; }
 template <bool STATS, uint32_t FEAT, uint32_t MODE = MODE_GENERIC>
 __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WAVES)) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm_in, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, float* __restrict__ partial, unsigned* __restrict__ work_counter,
-                                                DevStats* __restrict__ stats, PathOut pout) {
+                                                DevStats* __restrict__ stats, PathOut pout, float4* __restrict__ defer_buf) {
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
 #ifndef PT_FILM_PIX
 #define PT_FILM_PIX 64
@@ -149,11 +183,15 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     if constexpr (MODE == MODE_NEE_SOBOL) { prm.strategy = 1u; prm.sampler = 1u; }
     if constexpr (MODE == MODE_PT) prm.strategy = 0u;                      // either sampler
     const uint32_t lane = threadIdx.x;
-    auto park = [&](Path& Q) {
+    auto park = [&](Path& Q, bool mine = true) {      // `mine`: this lane's record is stored (a second shading pass only stores the lanes it shaded)
         if constexpr (PARK) {
+            if (mine) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s_park[i * 64 + lane] = Q.pf[i]; Q.pf[i] = 0.0f; }
-            s_park[4 * 64 + lane] = Q.p_pdf; s_park[5 * 64 + lane] = Q.prev_pos.x; s_park[6 * 64 + lane] = Q.prev_pos.y; s_park[7 * 64 + lane] = Q.prev_pos.z;
+                for (int i = 0; i < 4; ++i) s_park[i * 64 + lane] = Q.pf[i];
+                s_park[4 * 64 + lane] = Q.p_pdf; s_park[5 * 64 + lane] = Q.prev_pos.x; s_park[6 * 64 + lane] = Q.prev_pos.y; s_park[7 * 64 + lane] = Q.prev_pos.z;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Q.pf[i] = 0.0f;
             Q.p_pdf = 0.0f; Q.prev_pos = mk3(0.0f, 0.0f, 0.0f);
         }
     };
@@ -228,10 +266,26 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
         // `susp` (carry-over): this lane's closest-hit ray is still in flight, the lane sits out the shading stage
         bool dying = false, susp = false;
         CarryState carry{0ull};
+        constexpr uint32_t DEFER = defer_classes<FEAT, MODE>();
+        float4* const q_base = DEFER ? defer_buf + (size_t)blockIdx.x * (DEFER_RING * DEFER_F4) : nullptr;     // this wave's queue
+        uint32_t q_head = 0u, q_tail = 0u;                         // wave-uniform; the queue is empty between work items
         while (true) {
             unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
             uint32_t bsdf_classes = 0u;
             if (STATS) ts0 = __builtin_amdgcn_s_memtime();
+            // deferral queue: when enough paths wait (or nothing new is left to start), this iteration's free lanes take them
+            bool popped = false, drain = false;
+            uint32_t pop_e = 0u;
+            if constexpr (DEFER != 0u) {
+                const uint32_t q_count = q_tail - q_head;
+                drain = PT_DEFER == 1 && !(STATS && prm.stats_mode == 1u) && (q_count >= (uint32_t)PT_DEFER_MIN || (pool_next >= pool_size && q_count != 0u));
+                if (drain) {
+                    const unsigned long long m_free = __ballot(!active);
+                    const uint32_t r = rank_below(m_free);
+                    if (!active && r < q_count) { popped = true; active = true; pop_e = (q_head + r) & (DEFER_RING - 1u); }   // its record is read after the traversal
+                    q_head += min((uint32_t)__popcll(m_free), q_count);
+                }
+            }
             const unsigned long long m_needy = __ballot(!active);
             if (m_needy != 0ull && pool_next < pool_size) {
                 const uint32_t idx = pool_next + rank_below(m_needy);
@@ -244,7 +298,11 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 }
                 pool_next = min(pool_next + (uint32_t)__popcll(m_needy), pool_size);
             }
-            if (!__any(active)) { if (pool_next >= pool_size) break; continue; }
+            if (!__any(active)) {
+                if (pool_next >= pool_size && q_tail == q_head) break;
+                // (PT_DEFER 2 takes queued paths AFTER the shading stage: with nothing left to start, an iteration without rays still has to get there)
+                if (!(DEFER != 0u && PT_DEFER == 2 && pool_next >= pool_size)) continue;
+            }
             if (STATS) { ts1 = __builtin_amdgcn_s_memtime(); if (lane == 0) st.w[4]++; if (active) st.w[5]++; }
             Hit hit{};
             bool got = false;
@@ -255,7 +313,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 bool occluded = false;
                 if (STATS && sh.on) st.w[6]++;
                 PT_PRIO_TRAV_ENTER;
-                trace_pair_coop<STATS, wide_bvh<FEAT>(), CARRY>(sc, P.ro, P.rd, active && !dying, sh.o, sh.d, sh.t, sh.on, stack, lane, pair_lds, hit, got, occluded, st, &carry, susp, &susp);
+                trace_pair_coop<STATS, wide_bvh<FEAT>(), CARRY>(sc, P.ro, P.rd, active && !dying && !popped, sh.o, sh.d, sh.t, sh.on, stack, lane, pair_lds, hit, got, occluded, st, &carry, susp, &susp);
                 PT_PRIO_TRAV_EXIT;
                 if (sh.on && !occluded) {
 #pragma unroll
@@ -276,10 +334,53 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 bsdf_classes = classes - (__ballot(mclass == MT_EMISSIVE) != 0ull ? 1u : 0u);
                 ts2 = __builtin_amdgcn_s_memtime();
             }
-            bool end_path = MERGED && dying;           // a dying path's last connection has just been resolved
-            if constexpr (!MERGED) sh = ShadowReq{};
-            const bool shade_now = active && !(MERGED && (dying || susp));
-            unpark(P);
+            // The shading stage.  PT_DEFER 2 runs it a second time in the iterations that shade the deferral queue: the lanes the first pass
+            // freed (ended paths, deferred hits) take queued paths and shade them at once, so a queued path rejoins the NEXT traversal
+            // with its next ray like everybody else (PT_DEFER 1 pops at the top of the iteration and lets those lanes sit out a traversal).
+            for (int pass = 0;; ++pass) {
+            const bool mine = pass == 0 || popped;     // the lanes this pass works on
+            bool end_path = pass == 0 && MERGED && dying;           // a dying path's last connection has just been resolved
+            if (pass == 0) {
+                if constexpr (!MERGED) sh = ShadowReq{};
+                unpark(P);
+            }
+            if constexpr (DEFER != 0u) {
+                // queued paths join here: path state, hit and pixel of the lanes that popped (PT_DEFER 1: registers dead during the traversal)
+                if (popped) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const float4* r = q_base + (size_t)pop_e * DEFER_F4;
+                    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6], h = r[7];
+                    const uint32_t fl = __float_as_uint(b.y);
+                    P.smp.morton = __float_as_uint(a.x); P.smp.dimension = __float_as_uint(a.y); P.smp.rkey_lo = __float_as_uint(a.z); P.smp.rkey_hi = __float_as_uint(a.w);
+                    P.wl.lam0 = b.x; P.wl.term = (fl & 1u) != 0u; P.from_camera = (fl & 2u) != 0u; P.prev_spec = (fl & 4u) != 0u; P.depth = (fl >> 8) & 255u; my_pix = fl >> 16;
+                    P.T[0] = b.z; P.T[1] = b.w; P.T[2] = c.x; P.T[3] = c.y; P.L[0] = c.z; P.L[1] = c.w; P.L[2] = d.x; P.L[3] = d.y;
+                    P.rd = mk3(d.z, d.w, e.x); P.ro = mk3(0.0f, 0.0f, 0.0f);
+                    P.pf[0] = e.y; P.pf[1] = e.z; P.pf[2] = e.w; P.pf[3] = f.x; P.p_pdf = f.y; P.prev_pos = mk3(f.z, f.w, g.x);
+                    hit.t = g.y; hit.b0 = g.z; hit.b1 = g.w; hit.b2 = h.x; hit.tri = __float_as_uint(h.y); hit.mclass = __float_as_uint(h.z);
+                    got = true;
+                }
+                // and the lanes whose hit is on a deferred material leave (unless this is the iteration that shades the queue)
+                const bool defer_now = pass == 0 && !drain && !(STATS && prm.stats_mode == 1u) && active && !dying && !susp && !popped && got && ((DEFER >> (hit.mclass & 31u)) & 1u) != 0u;
+                const unsigned long long m_def = __ballot(defer_now);
+                if (m_def != 0ull) {
+                    if (defer_now) {
+                        float4* r = q_base + (size_t)((q_tail + rank_below(m_def)) & (DEFER_RING - 1u)) * DEFER_F4;
+                        const uint32_t fl = (P.wl.term ? 1u : 0u) | (P.from_camera ? 2u : 0u) | (P.prev_spec ? 4u : 0u) | ((P.depth & 255u) << 8) | (my_pix << 16);
+                        r[0] = make_float4(__uint_as_float(P.smp.morton), __uint_as_float(P.smp.dimension), __uint_as_float(P.smp.rkey_lo), __uint_as_float(P.smp.rkey_hi));
+                        r[1] = make_float4(P.wl.lam0, __uint_as_float(fl), P.T[0], P.T[1]);
+                        r[2] = make_float4(P.T[2], P.T[3], P.L[0], P.L[1]);
+                        r[3] = make_float4(P.L[2], P.L[3], P.rd.x, P.rd.y);
+                        r[4] = make_float4(P.rd.z, P.pf[0], P.pf[1], P.pf[2]);
+                        r[5] = make_float4(P.pf[3], P.p_pdf, P.prev_pos.x, P.prev_pos.y);
+                        r[6] = make_float4(P.prev_pos.z, hit.t, hit.b0, hit.b1);
+                        r[7] = make_float4(hit.b2, __uint_as_float(hit.tri), __uint_as_float(hit.mclass), 0.0f);
+                        active = false;                                      // free: a new path (or a queued one) next
+                    }
+                    q_tail += (uint32_t)__popcll(m_def);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                }
+            }
+            const bool shade_now = mine && active && !(MERGED && (dying || susp));
             if constexpr ((FEAT & FEAT_CC) != 0u) {
                 ShadeCtx C;
                 C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
@@ -292,7 +393,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             } else {
                 if (shade_now) end_path = shade_vertex<STATS, FEAT>(P, sc, prm, sctx, got, hit, sh, st, tsa, tsb);
             }
-            park(P);
+            park(P, mine);
             if (STATS) {
                 ts3 = __builtin_amdgcn_s_memtime();
                 // the stamps inside shade_vertex are taken by the lanes that reach them: make them wave-level (first lane that has one)
@@ -307,8 +408,10 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
             if (MERGED && !canonical) {
                 // merged form: the connection of a CONTINUING path waits for the next iteration's traversal; a path that ends here with a
                 // connection pending (a failed BSDF sample after the light was sampled: rare) lives on for that traversal alone
-                dying = sh.on && end_path;
-                if (dying) end_path = false;
+                if (mine) {
+                    dying = sh.on && end_path;
+                    if (dying) end_path = false;
+                }
             } else {
                 // two traversals per iteration — and everything in the canonical-count mode: the connection is traced now
                 const bool now = sh.on;
@@ -325,7 +428,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 }
             }
             if (STATS) ts4 = __builtin_amdgcn_s_memtime();
-            if (active && end_path) {
+            if (mine && active && end_path) {
                 if (pout.L != nullptr) {
                     // per-sample log (see PathOut): the sample index is the low log2(spp) bits of the lane's Morton index (spp a power of two)
                     const uint32_t px = job0.px + (my_pix & blk_mask), py = job0.py + (my_pix >> blk_log2);
@@ -337,6 +440,19 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
                 film_rgb(P, sc, prm, r, g, b);
                 atomicAdd(&s_film[3 * my_pix], r); atomicAdd(&s_film[3 * my_pix + 1], g); atomicAdd(&s_film[3 * my_pix + 2], b);
                 active = false;
+            }
+            // a second pass for the deferral queue?
+            if constexpr (DEFER != 0u && PT_DEFER == 2) {
+                if (pass != 0 || (STATS && prm.stats_mode == 1u)) break;
+                const uint32_t q_count = q_tail - q_head;
+                if (!(q_count >= (uint32_t)PT_DEFER_MIN || (pool_next >= pool_size && q_count != 0u))) break;
+                const unsigned long long m_free = __ballot(!active);
+                if (m_free == 0ull) break;
+                const uint32_t r = rank_below(m_free);
+                popped = !active && r < q_count;
+                if (popped) { active = true; dying = false; pop_e = (q_head + r) & (DEFER_RING - 1u); }
+                q_head += min((uint32_t)__popcll(m_free), q_count);
+            } else break;
             }
             if (STATS) {
                 unsigned long long ts5 = __builtin_amdgcn_s_memtime();
@@ -377,14 +493,14 @@ inline uint32_t pick_features(uint32_t feat) {
 }
 struct PtLaunchArgs {
     DevScene sc; DevCamera cam; DevParams prm; const uint64_t* d_hash; float* d_accum; float* d_partial; unsigned* d_counter; DevStats* d_stats;
-    int grid; hipStream_t stream; PathOut pout;
+    int grid; hipStream_t stream; PathOut pout; float4* d_defer;
 };
 // The feature sets in two classes, compiled in separate translation units with their own backend options (Makefile): the sets without the
 // clearcoat code run at 4 waves per SIMD and gain from sinking / the AMDGPU pressure trackers, the clearcoat sets (3 waves per SIMD) lose.
 #define PT_FOR_EACH_PLAIN_SET(X) X(0u) X(FEAT_TEX) X(FEAT_DIEL) X(FEAT_METAL) X(FEAT_DIEL | FEAT_ROUGH) X(FEAT_DELTA | FEAT_MLIGHT) X(FEAT_STD & ~FEAT_CC)
 #define PT_FOR_EACH_CC_SET(X) X(FEAT_CC) X(FEAT_CC | FEAT_TEX) X(FEAT_STD) X(FEAT_ALL)
 #define PT_FOR_EACH_FEATURE_SET(X) PT_FOR_EACH_PLAIN_SET(X) PT_FOR_EACH_CC_SET(X)
-#define PT_CASE(F) case (F): hipLaunchKernelGGL((pt_kernel<false, (F), MODE>), dim3(a.grid), dim3(64), 0, a.stream, a.sc, a.cam, a.prm, a.d_hash, a.d_accum, a.d_partial, a.d_counter, a.d_stats, a.pout); break;
+#define PT_CASE(F) case (F): hipLaunchKernelGGL((pt_kernel<false, (F), MODE>), dim3(a.grid), dim3(64), 0, a.stream, a.sc, a.cam, a.prm, a.d_hash, a.d_accum, a.d_partial, a.d_counter, a.d_stats, a.pout, a.d_defer); break;
 template <uint32_t MODE>
 void launch_pt_plain(const PtLaunchArgs& a, uint32_t feat) {
     switch (pick_features(feat)) { PT_FOR_EACH_PLAIN_SET(PT_CASE) default: break; }

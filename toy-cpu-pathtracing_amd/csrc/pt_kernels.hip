@@ -161,15 +161,15 @@ __global__ void combine_kernel(DevCamera cam, DevParams prm, const float* __rest
 // launch wrappers (host side, called from api.cpp)
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_pt(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const uint64_t* d_hash, float* d_accum, float* d_partial,
-                     unsigned* d_counter, DevStats* d_stats, bool stats, uint32_t feat, int grid, hipStream_t stream, const PathOut& pout) {
-    const PtLaunchArgs a{sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, grid, stream, pout};
+                     unsigned* d_counter, DevStats* d_stats, bool stats, uint32_t feat, int grid, hipStream_t stream, const PathOut& pout, float* d_defer) {
+    const PtLaunchArgs a{sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, grid, stream, pout, (float4*)d_defer};
     if (stats) {
         // two instrumented variants: scenes without the clearcoat code get the one whose traversal has the production form (merged, 4 waves
         // per SIMD), so that the lane-use diagnostics describe what the benchmarked kernels do
         if ((feat & (FEAT_CC | FEAT_EMTEX)) == 0u)
-            hipLaunchKernelGGL((pt_kernel<true, FEAT_STD & ~FEAT_CC, MODE_GENERIC>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout);
+            hipLaunchKernelGGL((pt_kernel<true, FEAT_STD & ~FEAT_CC, MODE_GENERIC>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout, a.d_defer);
         else
-            hipLaunchKernelGGL((pt_kernel<true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout);
+            hipLaunchKernelGGL((pt_kernel<true, FEAT_ALL>), dim3(grid), dim3(64), 0, stream, sc, cam, prm, d_hash, d_accum, d_partial, d_counter, d_stats, pout, a.d_defer);
     } else if (prm.sampler == 1u && prm.strategy == 2u) launch_pt_mis_sobol(a, feat);
     else if (prm.sampler == 1u && prm.strategy == 1u) launch_pt_nee_sobol(a, feat);
     else if (prm.strategy == 0u) launch_pt_strategy_pt(a, feat);
@@ -233,6 +233,7 @@ hipError_t launch_probe_occluded(const DevScene& sc, const float* o, const float
 
 namespace pt {
 uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed) { return murmur_dim_seed(dimension, seed); }
+size_t query_defer_bytes_per_wave() { return defer_bytes_per_wave(); }     // the deferral queues of pt_kernel.hpp (0: compiled out)
 // resident 64-thread blocks (= waves) on the current device of the EXACT kernel instantiation launch_pt takes for (stats, feat, sampler,
 // strategy): the persistent grid size.  The MODE specialisations are separate translation units with their own backend flags, so their
 // register counts — and with them the occupancy — need not be those of the generic variant.  Cached per scene and device (api.cpp LaunchCtx).

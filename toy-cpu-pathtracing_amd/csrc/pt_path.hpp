@@ -443,9 +443,10 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
         }
         if (!end_path) {
             if (STATS) { st.bounces++; tsa = __builtin_amdgcn_s_memtime(); }
-            Frame fr, fw;
-            if constexpr (numeric_frames<FEAT>()) shading_frames_numeric(sf.ns, sf.tangent, fr, fw);
-            else { fr = shading_frame(sf.ns, sf.tangent); fw = fr; }
+            Frame fr, fw_num;
+            if constexpr (numeric_frames<FEAT>()) shading_frames_numeric(sf.ns, sf.tangent, fr, fw_num);
+            else fr = shading_frame(sf.ns, sf.tangent);
+            const Frame& fw = numeric_frames<FEAT>() ? fw_num : fr;           // (the transpose form has ONE matrix: no second copy in ShadeCtx)
             f3 wo_r = -rd;                                                    // Intersection.wo
             f3 wo = to_local(fr, wo_r);
             f3 ng_t = normalize(to_local(fw, sf.ng));                         // Transform * Normal: inverse-transpose, then renormalised
@@ -482,7 +483,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             }
             f3 wo_nm = to_local(nf, wo);
             // ---- hand-over to the second half ----
-            C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; C.fw = fw; C.nf = nf; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
+            C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; if constexpr (numeric_frames<FEAT>()) C.fw = fw_num; C.nf = nf; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
             C.geo_wo = dot(ng_t, wo); C.uc = uc; C.uv = uv; C.is_diel = is_diel; C.rough_diel = rough_diel; C.d_alpha = d_alpha; C.cont = true;
             if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) {
                 // SimpleClearcoatPbrMaterial: FloatParameter values at the shading point + the inputs of the coat's directional albedo
@@ -525,7 +526,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
     bool& do_shadow = sh.on; f3& sh_o = sh.o; f3& sh_d = sh.d; float& sh_t = sh.t; float* sh_c = sh.c;
     (void)L; (void)from_camera;
     const Surface& sf = C.sf; const DevMaterial* mat = C.mat; const uint32_t mtype = C.mtype;
-    const Frame& fr = C.fr; const Frame& fw = C.fw; const Frame& nf = C.nf; const f3 wo = C.wo, wo_nm = C.wo_nm, ng_t = C.ng_t;
+    const Frame& fr = C.fr; const Frame& fw = numeric_frames<FEAT>() ? C.fw : C.fr; const Frame& nf = C.nf; const f3 wo = C.wo, wo_nm = C.wo_nm, ng_t = C.ng_t;
     const float uc = C.uc; const f2 uv = C.uv; const bool is_diel = C.is_diel, rough_diel = C.rough_diel;
     {
         {
