@@ -716,3 +716,19 @@ def test_bench_n_gpus_reproduces_the_one_gpu_film_bit_for_bit():
         assert j["n_gpus"] == n and j["film_check"] and j["film_check"]["mean"] > 0.01
         digests[n] = j["film_check"]["sha256"]
     assert digests[1] == digests[2], digests
+
+
+def test_rr_gate_slack_is_refused_unless_unlocked(product, pkg):
+    """mi355pt_params.rr_gate_slack changes what a render call computes; a drop-in caller's uninitialised struct must not be able to do
+    that by accident: the library refuses a non-zero value unless mi355pt_debug_unlock(1) (include/mi355pt_debug.h) was called."""
+    sc = product.new_scene()
+    cam = pkg.scenes.load_scene(sc, 0, 32, 24)
+    prm = pkg.make_params(4, "mis", "sobol", rr_gate_slack=1e-5)
+    was = product.debug_unlock(False)
+    try:
+        with pytest.raises(RuntimeError, match="rr_gate_slack must be 0"):
+            product.render(sc, cam, prm)
+        product.render(sc, cam, pkg.make_params(4, "mis", "sobol"))          # the reference's gate needs no switch
+    finally:
+        product.debug_unlock(was)
+    product.render(sc, cam, prm)

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/mi355pt.h"
+#include "../../include/mi355pt_debug.h"
 #include "layout.hpp"
 #include "scene.hpp"
 
@@ -31,6 +32,7 @@ int query_resident_waves(bool stats, uint32_t feat, uint32_t sampler, uint32_t s
 using namespace pt;
 
 static thread_local std::string g_err;
+static bool g_debug_unlocked = false;      // mi355pt_debug_unlock: lets mi355pt_params.rr_gate_slack through
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -204,6 +206,8 @@ int check_args(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_
     if (cam->width == 0 || cam->height == 0 || p->spp == 0) return fail(MI355PT_E_INVALID, "empty image or spp == 0");
     if (p->strategy > 2 || p->sampler > 1) return fail(MI355PT_E_INVALID, "bad strategy/sampler");
     if (!(p->rr_gate_slack >= 0.0f && p->rr_gate_slack < 1.0f)) return fail(MI355PT_E_INVALID, "rr_gate_slack must be in [0, 1)");
+    if (p->rr_gate_slack != 0.0f && !g_debug_unlocked)
+        return fail(MI355PT_E_INVALID, "mi355pt_params.rr_gate_slack must be 0 (a diagnostic: mi355pt_debug_unlock(1) in mi355pt_debug.h enables it)");
     if (p->shard_count && p->shard_index >= p->shard_count) return fail(MI355PT_E_INVALID, "bad shard");
     // mi355pt_scene_build bakes the world -> render translation (render space = world - camera position, camera.rs:84-86) into every
     // device record and uploads to the device that was current then: a render call must name the same camera position and device
@@ -239,6 +243,7 @@ mi355pt_scene::~mi355pt_scene() {
 extern "C" {
 
 const char* mi355pt_last_error(void) { return g_err.c_str(); }
+int mi355pt_debug_unlock(int on) { const int was = g_debug_unlocked ? 1 : 0; g_debug_unlocked = on != 0; return was; }
 #ifndef MI355PT_BUILD_ID
 #define MI355PT_BUILD_ID "dev"
 #endif

@@ -108,11 +108,13 @@ def _ptr(a, ty):
     return a.ctypes.data_as(C.POINTER(ty)) if a is not None else None
 
 
-# every symbol include/mi355pt.h declares (tests/test_abi.py checks the built library exports all of them)
+# every symbol include/mi355pt.h declares (tests/test_abi.py checks the built library exports all of them) ...
+DEBUG_SYMBOLS = ["debug_unlock", "scene_export_bvh", "probe_bvh_collapse", "probe_bvh_collapse_nodes", "probe_sobol", "probe_intersect", "probe_occluded",
+                 "sample_log_records", "render_sample_log", "probe_radiance"]     # ... and include/mi355pt_debug.h
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
     "scene_add_material", "scene_add_instance", "scene_add_delta_light", "scene_add_environment_light", "scene_set_bvh_builder", "scene_build", "render", "render_accum_device", "film_resolve_device",
-    "quantize_u8", "scene_info", "probe_sobol", "probe_intersect", "probe_occluded", "probe_radiance", "sample_log_records", "render_sample_log", "scene_build_multi", "render_multi", "scene_export_bvh", "coat_albedo_table", "probe_bvh_collapse", "probe_bvh_collapse_nodes",
+    "quantize_u8", "scene_info", "scene_build_multi", "render_multi", "coat_albedo_table",
     "last_error", "version",
 ]
 
@@ -307,14 +309,19 @@ class Product(Backend):
         lib.mi355pt_film_resolve_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         if not hasattr(lib, "mi355pt_render_sample_log"):      # an older build loaded through MI355PT_LIB for an A/B timing run
             return
-        if not hasattr(lib, "mi355pt_render_sample_log"):      # an older build loaded through MI355PT_LIB for an A/B timing run
-            return
         lib.mi355pt_sample_log_records.argtypes = [C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]
         lib.mi355pt_render_sample_log.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32] + \
             [C.POINTER(C.c_float)] * 3 + [C.c_size_t, C.POINTER(C.c_float)]
 
     def version(self):
         return self.lib.mi355pt_version().decode()
+
+    def debug_unlock(self, on=True):
+        """mi355pt_debug_unlock (mi355pt_debug.h): lets params.rr_gate_slack through; returns the previous state.  The parity tests that
+        relax the Russian-roulette gate switch it on for themselves (tests/conftest.py `product` fixture)."""
+        if not hasattr(self.lib, "mi355pt_debug_unlock"):      # an older build loaded through MI355PT_LIB
+            return True
+        return bool(self.lib.mi355pt_debug_unlock(1 if on else 0))
 
     def scene_info(self, scene):
         buf = C.create_string_buffer(256)
