@@ -61,6 +61,24 @@ static_assert(sizeof(DevNode4) == 128, "wide node must be 128 B");
 #define PT_NODE_FMA 0
 #endif
 constexpr float NODE4_PAD_REL = 9.5367431640625e-07f;   // 2^-20
+// PT_NODE_Q16 1: the cooperative traversals read a 64-BYTE node — the four child boxes as 16-bit planes on ONE grid over the scene's
+// bounds (lo planes snapped down, hi planes up, so a quantised box contains its box), 4 x dwordx4 per lane and node step instead of 7;
+// dequantisation is free (t = q * (cell / d) + (origin - o) / d: one fma on the converted integer, SDWA word select in the conversion).
+// Layout: for each axis one 16-byte row {lo[0..3], hi[0..3]} as u16, then the four links; unused slots lo = 65535, hi = 0.
+// Built, parity-green (160 GPU tests) and MEASURED SLOWER (round 3, same box): scene 3 2 076 -> 1 861, scenes 10 / 8 -10 %, scene 17 -8 %.
+// Two reasons, both in the counters: (1) a grid cell of the Cornell room is 1.8e-4, eighteen times RAY_EPS — the flat leaf boxes of the
+// walls become slabs that CONTAIN the origins of the rays leaving them, so every bounce off a wall tests the wall's own triangles again
+// (triangle tests per sample 8.4 -> 12.1 closest, 3.1 -> 6.5 shadow: +2.2 dense triangle steps per iteration); (2) the node steps themselves
+// got no faster with 43 % fewer L1 requests — like round 2's 32-byte nodes.  (An ablation that ADDS requests, PT_ABLATE_EXTRA_NODE_LOADS,
+// loses 9 % per 3 requests, but it also adds 12 live registers; the two quantisation experiments say the request count is not the lever.)
+#ifndef PT_NODE_Q16
+#define PT_NODE_Q16 0
+#endif
+struct alignas(16) DevNode4Q {
+    uint16_t q[3][2][4];     // [axis][0 = lo, 1 = hi][child]
+    int32_t child[4];
+};
+static_assert(sizeof(DevNode4Q) == 64, "quantised wide node must be 64 B");
 PT_HD inline int32_t make_leaf(uint32_t first, uint32_t count) { return (int32_t)(0x80000000u | (first << 3) | (count - 1)); }
 PT_HD inline uint32_t leaf_first(int32_t c) { return ((uint32_t)c & 0x7fffffffu) >> 3; }
 PT_HD inline uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1; }
@@ -169,7 +187,9 @@ struct DevEnv {
 
 struct DevScene {
     const DevNode* nodes;         // BVH2: the plain traversals (probes, canonical step counts)
-    const DevNode4* nodes4;       // the same tree collapsed to <= 4 children per node: the render path's cooperative traversals
+    const DevNode4* nodes4;       // the same tree collapsed to <= 4 children per node: the render path's cooperative traversals (PT_NODE_Q16 0)
+    const DevNode4Q* nodes4q;     // ... with its boxes on the 16-bit scene grid (PT_NODE_Q16 1: what the traversals read)
+    float grid_org[3], grid_cell[3];   // plane = grid_org + q * grid_cell
     const DevTri* tris;
     const DevTriShade* shade;
     const DevInstance* instances;

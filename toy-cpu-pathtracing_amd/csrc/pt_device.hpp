@@ -601,6 +601,40 @@ struct Node4Hits { float n[4]; int32_t link[4]; };
 #ifndef PT_NODE_SEL
 #define PT_NODE_SEL 1
 #endif
+#if PT_NODE_Q16
+// The quantised form (layout.hpp DevNode4Q): `ro` holds (grid origin - o) / d and `inv` cell / d (walk_ray below), so a plane's distance is
+// one fma on the converted 16-bit integer.  Four requests: the x, y, z rows (lo and hi planes of the four children in ONE 16-byte row each)
+// and the links; near / far are chosen by the sign of the direction among the row's two halves.
+PT_DEV Node4Hits node4q_step(const DevNode4Q* nodes, int32_t cur, f3 ro, f3 inv, float t_lim) {
+    const uint4* q = (const uint4*)(nodes + cur);
+    const uint4 X = q[0], Y = q[1], Z = q[2];
+    const int4 ch = *(const int4*)(q + 3);
+#if PT_NODE_LOADS_FIRST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;        // (cell > 0: the sign of cell / d is the sign of d; -0 counts as +)
+    const uint32_t nx01 = sx ? X.z : X.x, nx23 = sx ? X.w : X.y, fx01 = sx ? X.x : X.z, fx23 = sx ? X.y : X.w;
+    const uint32_t ny01 = sy ? Y.z : Y.x, ny23 = sy ? Y.w : Y.y, fy01 = sy ? Y.x : Y.z, fy23 = sy ? Y.y : Y.w;
+    const uint32_t nz01 = sz ? Z.z : Z.x, nz23 = sz ? Z.w : Z.y, fz01 = sz ? Z.x : Z.z, fz23 = sz ? Z.y : Z.w;
+#define PT_QLO(v) ((float)((v) & 0xffffu))
+#define PT_QHI(v) ((float)((v) >> 16))
+#define PT_SLABQ(NXW, NYW, NZW, FXW, FYW, FZW, H, N, F)                                                                                   \
+    N = fmaxf(fmaxf(fmaxf(fmaf(H(NXW), inv.x, ro.x), fmaf(H(NYW), inv.y, ro.y)), fmaf(H(NZW), inv.z, ro.z)), 0.0f);                       \
+    F = fminf(fminf(fminf(fmaf(H(FXW), inv.x, ro.x), fmaf(H(FYW), inv.y, ro.y)), fmaf(H(FZW), inv.z, ro.z)), t_lim);
+    float n0, n1, n2, n3, f0, f1, f2, f3_;
+    PT_SLABQ(nx01, ny01, nz01, fx01, fy01, fz01, PT_QLO, n0, f0)
+    PT_SLABQ(nx01, ny01, nz01, fx01, fy01, fz01, PT_QHI, n1, f1)
+    PT_SLABQ(nx23, ny23, nz23, fx23, fy23, fz23, PT_QLO, n2, f2)
+    PT_SLABQ(nx23, ny23, nz23, fx23, fy23, fz23, PT_QHI, n3, f3_)
+#undef PT_SLABQ
+#undef PT_QLO
+#undef PT_QHI
+    Node4Hits h;
+    h.n[0] = n0 <= f0 ? n0 : INFINITY; h.n[1] = n1 <= f1 ? n1 : INFINITY; h.n[2] = n2 <= f2 ? n2 : INFINITY; h.n[3] = n3 <= f3_ ? n3 : INFINITY;
+    h.link[0] = ch.x; h.link[1] = ch.y; h.link[2] = ch.z; h.link[3] = ch.w;
+    return h;
+}
+#endif
 PT_DEV Node4Hits node4_step(const DevNode4* nodes, int32_t cur, f3 ro, f3 inv, float t_lim) {
     // CONTRACT: t_lim <= 1e30 (every caller clamps its limit once per ray, not once per step: trace_any_deferred / trace_closest_coop /
     // trace_pair_coop initialise and only ever shrink w_t / w_tmax / w_tbest from min(t, 1e30)).
@@ -617,6 +651,16 @@ PT_DEV Node4Hits node4_step(const DevNode4* nodes, int32_t cur, f3 ro, f3 inv, f
     // box arithmetic (fewer live registers) and the step then waits for a SECOND L1 round trip at its very end
 #ifndef PT_NODE_LOADS_FIRST
 #define PT_NODE_LOADS_FIRST 1
+#endif
+#ifdef PT_ABLATE_EXTRA_NODE_LOADS   // timing experiment: N more 16-B requests per lane and node step (same cache line, results unused) — how
+    {                               // much does a node step's time depend on the NUMBER of L1 requests?  
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f extra[PT_ABLATE_EXTRA_NODE_LOADS];
+#pragma unroll
+        for (int e = 0; e < PT_ABLATE_EXTRA_NODE_LOADS; ++e) extra[e] = *(const volatile v4f*)(base + o + 112 - 16 * (e % 7));
+#pragma unroll
+        for (int e = 0; e < PT_ABLATE_EXTRA_NODE_LOADS; ++e) asm volatile("" ::"v"(extra[e]));
+    }
 #endif
 #if PT_NODE_LOADS_FIRST
     __builtin_amdgcn_sched_barrier(0);
@@ -658,9 +702,23 @@ PT_DEV Node4Hits node4_step(const DevNode4* nodes, int32_t cur, f3 ro, f3 inv, f
 #error "PT_NODE_FMA needs PT_NODE_SEL"
 #endif
 template <bool WIDE>
-PT_DEV f3 walk_origin(f3 ro, f3 inv) {
+PT_DEV f3 walk_origin(const DevScene& sc, f3 ro, f3 inv) {
+    if (WIDE && PT_NODE_Q16) return mk3((sc.grid_org[0] - ro.x) * inv.x, (sc.grid_org[1] - ro.y) * inv.y, (sc.grid_org[2] - ro.z) * inv.z);
     if (WIDE && PT_NODE_FMA) return mk3(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
     return ro;
+}
+// ... and as its reciprocal direction: 1 / d, or with PT_NODE_Q16 the grid cell over d
+template <bool WIDE>
+PT_DEV f3 walk_inv(const DevScene& sc, f3 inv) {
+    if (WIDE && PT_NODE_Q16) return mk3(sc.grid_cell[0] * inv.x, sc.grid_cell[1] * inv.y, sc.grid_cell[2] * inv.z);
+    return inv;
+}
+PT_DEV Node4Hits wide_step(const DevScene& sc, int32_t cur, f3 wo, f3 wi, float t_lim) {
+#if PT_NODE_Q16
+    return node4q_step(sc.nodes4q, cur, wo, wi, t_lim);
+#else
+    return node4_step(sc.nodes4, cur, wo, wi, t_lim);
+#endif
 }
 // nearest child to slot 0 (PT_SORT_MODE 1) or ascending by entry distance (0); misses (+inf) are skipped by the pushes
 // stack pushes of the 4-wide step as stores-always / advance-conditionally: a slot written for a miss lies above the top and is never read
@@ -717,7 +775,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
     // the ray this lane is WALKING (its own, or one it is helping with) — the lane's own ray stays in ro/rd/rs for the flushes
     // (box tests only see distances up to 1e30: the unused slots of a DevNode4 are point boxes at FLT_MAX, whose slab distance FLT_MAX / |d|
     // must never fall inside [0, t_lim] — an unbounded shadow ray (t_max = FLT_MAX, directional and environment lights) would let it)
-    f3 w_ro = walk_origin<WIDE>(ro, rs.inv), w_inv = rs.inv; float w_tmax = fminf(t_max, 1e30f); uint32_t owner = lane;
+    f3 w_ro = walk_origin<WIDE>(sc, ro, rs.inv), w_inv = walk_inv<WIDE>(sc, rs.inv); float w_tmax = fminf(t_max, 1e30f); uint32_t owner = lane;
     int sp = 0, sb = 0;
     int32_t cur = WIDE ? sc.root4 : sc.root;
     uint32_t leaf_off = 0;                    // triangles of the current leaf already queued
@@ -751,7 +809,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
         if (!done && cur >= 0) {
             if constexpr (WIDE) {
                 if (STATS) { st.nodes_shadow++; const int busy = __popcll(__ballot(true)); if (wave_leader()) { st.w[2]++; st.hist[8 + ((busy - 1) >> 3)]++; } }
-                const Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_tmax);
+                const Node4Hits h = wide_step(sc, cur, w_ro, w_inv, w_tmax);
                 // any-hit needs no order: continue into the first child hit, queue the others
                 int32_t nxt = 0; bool have = false;
     #pragma unroll
@@ -864,7 +922,7 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
     const uint32_t kpack = (uint32_t)rs.kx | ((uint32_t)rs.ky << 2) | ((uint32_t)rs.kz << 4);
     L.best[lane] = (0x7f7fffffull << 32) | 0xffffffffull;                 // (FLT_MAX, no triangle)
     __syncthreads();
-    f3 w_ro = walk_origin<WIDE>(ro, rs.inv), w_inv = rs.inv; float w_tbest = 1e30f; uint32_t owner = lane;             // box-test limit, see trace_any_deferred
+    f3 w_ro = walk_origin<WIDE>(sc, ro, rs.inv), w_inv = walk_inv<WIDE>(sc, rs.inv); float w_tbest = 1e30f; uint32_t owner = lane;             // box-test limit, see trace_any_deferred
     int sp = 0, sb = 0;
     int32_t cur = WIDE ? sc.root4 : sc.root;
     uint32_t leaf_off = 0;
@@ -898,7 +956,7 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
         if (!done && cur >= 0) {
             if constexpr (WIDE) {
                 if (STATS) { st.nodes_closest++; const int busy = __popcll(__ballot(true)); if (wave_leader()) { st.w[0]++; st.hist[0 + ((busy - 1) >> 3)]++; } }
-                Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_tbest);
+                Node4Hits h = wide_step(sc, cur, w_ro, w_inv, w_tbest);
                 sort4(h);
                 // nearest child next; the others go to the stack farthest first, so that the nearer of them is popped first
 #if PT_PUSH_BRANCHFREE
@@ -1067,7 +1125,7 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
     constexpr bool SFIRST = PT_SHADOW_FIRST != 0;
     constexpr bool PC = CARRY > 0 || SFIRST;                              // pend_c can be set at all
     const bool first_c = SFIRST ? (c_fresh && !s_want) : c_fresh;       // the ray the lane starts with is its closest-hit ray
-    f3 w_inv = first_c ? crs.inv : srs.inv, w_ro = walk_origin<WIDE>(first_c ? c_ro : s_ro, w_inv);
+    f3 w_ro = walk_origin<WIDE>(sc, first_c ? c_ro : s_ro, first_c ? crs.inv : srs.inv), w_inv = walk_inv<WIDE>(sc, first_c ? crs.inv : srs.inv);
     float w_t = first_c ? 1e30f : fminf(s_tmax, 1e30f);
     uint32_t ow = first_c ? lane : (lane | RAY_ANY);
     bool pend = !SFIRST && c_fresh && s_want, pend_c = SFIRST && c_fresh && s_want;
@@ -1141,7 +1199,7 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
         if (!done && cur >= 0) {
             if (STATS) { if (ow & RAY_ANY) st.nodes_shadow++; else st.nodes_closest++; const int busy = __popcll(__ballot(true)); if (wave_leader()) { st.w[0]++; st.hist[(busy - 1) >> 3]++; } }   // (the pool's steps are booked as closest-hit steps)
             if constexpr (WIDE) {
-                Node4Hits h = node4_step(sc.nodes4, cur, w_ro, w_inv, w_t);
+                Node4Hits h = wide_step(sc, cur, w_ro, w_inv, w_t);
                 sort4(h);                 // nearest first (any-hit does not need the order, and does not mind it)
 #if PT_PUSH_BRANCHFREE
                 stack[sp * 64] = (uint32_t)h.link[3]; sp += h.n[3] < INFINITY ? 1 : 0;
@@ -1202,12 +1260,12 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
         // a lane that ran dry starts its own pending ray (CARRY: the closest-hit ray it has not started yet, then the shadow ray)
         if (PC && done && pend_c && !(SFIRST && pend)) {
             pend_c = false; done = false;
-            w_ro = walk_origin<WIDE>(c_ro, crs.inv); w_inv = crs.inv; w_t = 1e30f; ow = lane;
+            w_ro = walk_origin<WIDE>(sc, c_ro, crs.inv); w_inv = walk_inv<WIDE>(sc, crs.inv); w_t = 1e30f; ow = lane;
             cur = root; sp = sb = 0; leaf_off = 0u;
         } else
         if (done && pend) {
             pend = false; done = false;
-            w_ro = walk_origin<WIDE>(s_ro, srs.inv); w_inv = srs.inv; w_t = fminf(s_tmax, 1e30f); ow = lane | RAY_ANY;
+            w_ro = walk_origin<WIDE>(sc, s_ro, srs.inv); w_inv = walk_inv<WIDE>(sc, srs.inv); w_t = fminf(s_tmax, 1e30f); ow = lane | RAY_ANY;
             cur = root; sp = sb = 0; leaf_off = 0u;
         }
         const unsigned long long m_act = __ballot(!done);
@@ -1233,8 +1291,9 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
                 // what this lane would give: its pending shadow ray from the root, else the bottom of its stack with its working ray
                 const bool give_c = PC && pend_c && !(SFIRST && pend);   // the own closest-hit ray not yet started (walking a carried context, or the shadow ray first)
                 const bool give_ray = pend || give_c;
-                const f3 g_inv = give_c ? crs.inv : (give_ray ? srs.inv : w_inv);
-                const f3 g_ro = give_ray ? walk_origin<WIDE>(give_c ? c_ro : s_ro, g_inv) : w_ro;
+                const f3 p_inv = give_c ? crs.inv : srs.inv;                      // the pending ray a lane would give away, in walking form
+                const f3 g_inv = give_ray ? walk_inv<WIDE>(sc, p_inv) : w_inv;
+                const f3 g_ro = give_ray ? walk_origin<WIDE>(sc, give_c ? c_ro : s_ro, p_inv) : w_ro;
                 const float g_t = give_c ? 1e30f : (give_ray ? fminf(s_tmax, 1e30f) : w_t);
                 const uint32_t g_ow = give_c ? lane : (give_ray ? (lane | RAY_ANY) : ow);
                 const int g_sb = give_ray ? -1 : sb;

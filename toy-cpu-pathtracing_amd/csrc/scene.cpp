@@ -475,7 +475,47 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             }
         }
 #endif
+#if PT_NODE_Q16
+        {   // the boxes on the 16-bit scene grid (layout.hpp PT_NODE_Q16): lo planes down, hi planes up, checked against the float boxes
+            auto used = [](const DevNode4& n, int c) { return n.lox[c] <= n.hix[c] && n.lox[c] < FLT_MAX; };
+            float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (const DevNode4& n : nodes4) for (int c = 0; c < 4; ++c) if (used(n, c)) {
+                const float l[3] = {n.lox[c], n.loy[c], n.loz[c]}, h[3] = {n.hix[c], n.hiy[c], n.hiz[c]};
+                for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], l[a]); hi[a] = std::fmax(hi[a], h[a]); }
+            }
+            float rmax = 0.0f;
+            for (int a = 0; a < 3; ++a) rmax = std::fmax(rmax, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+            // the fma slab test is off by up to 2 u max(|o|, |plane|) in space (layout.hpp PT_NODE_FMA): every plane moves out by `pad` more
+            const float pad = rmax * NODE4_PAD_REL;
+            for (int a = 0; a < 3; ++a) {
+                const float ext = std::fmax(hi[a] - lo[a], 1e-20f) + 4.0f * pad;
+                dev.grid_org[a] = lo[a] - 2.0f * pad;
+                dev.grid_cell[a] = ext / 65533.0f;
+            }
+            std::vector<DevNode4Q> q4(nodes4.size());
+            for (size_t i = 0; i < nodes4.size(); ++i) {
+                const DevNode4& n = nodes4[i]; DevNode4Q& q = q4[i];
+                for (int c = 0; c < 4; ++c) {
+                    q.child[c] = n.child[c];
+                    const float l[3] = {n.lox[c], n.loy[c], n.loz[c]}, h[3] = {n.hix[c], n.hiy[c], n.hiz[c]};
+                    for (int a = 0; a < 3; ++a) {
+                        if (!used(n, c)) { q.q[a][0][c] = 65535; q.q[a][1][c] = 0; continue; }
+                        const float org = dev.grid_org[a], cell = dev.grid_cell[a];
+                        long ql = (long)std::floor((l[a] - pad - org) / cell), qh = (long)std::ceil((h[a] + pad - org) / cell);
+                        ql = std::min<long>(std::max<long>(ql, 0), 65535); qh = std::min<long>(std::max<long>(qh, 0), 65535);
+                        // in the arithmetic the kernel sees (origin + q * cell in f32): the quantised planes enclose the padded box
+                        while (ql > 0 && org + (float)ql * cell > l[a] - pad) --ql;
+                        while (qh < 65535 && org + (float)qh * cell < h[a] + pad) ++qh;
+                        if (org + (float)ql * cell > l[a] || org + (float)qh * cell < h[a]) { *err = "internal error: quantised BVH box does not enclose its box"; return MI355PT_E_INVALID; }
+                        q.q[a][0][c] = (uint16_t)ql; q.q[a][1][c] = (uint16_t)qh;
+                    }
+                }
+            }
+            if ((rc = upload(this, q4, &dev.nodes4q, err))) return rc;
+        }
+#else
         if ((rc = upload(this, nodes4, &dev.nodes4, err))) return rc;
+#endif
         bvh4_nodes = nodes4.size();
     }
     if ((rc = upload(this, tris, &dev.tris, err))) return rc;
