@@ -139,7 +139,7 @@ typedef struct mi355pt_stats {
     uint64_t closest_hits, bounces, spectrum_evals, textured_lookups;
     /* diagnostic (collect_stats only): wave-cycles spent per phase of the wave state machine, summed over waves:
      * 0 regenerate (Sobol + camera ray), 1 closest-hit traversal, 2 shading + light sampling, 3 shadow traversal,
-     * 4 film/sensor, 5 whole loop; shading split: 6 surface+emission+RR, 7 BSDF sample, 8 light sample (NEE), 9 NOT cycles: closest-hit merges that met an exact tie in t between two triangles (the merge keeps the lower index) */
+     * 4 film/sensor, 5 whole loop; shading split: 6 surface+emission+RR, 7 BSDF sample, 8 light sample (NEE), 9 NOT cycles: low 32 bits = closest-hit merges that met an exact tie in t between two triangles (the merge keeps the lower index), high 32 bits = those between triangles of different material or normal */
     uint64_t phase_cycles[10];
     double kernel_ms; /* device time of the path-tracing launch(es), HIP events on the launch stream */
     uint32_t launches;

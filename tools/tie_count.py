@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("toy-cpu-pathtracing_amd")
 prod = pkg.Product()
 hip = C.CDLL("libamdhip64.so")
+# (scene 17: its instrumented kernel walks closest-hit rays alone (trace_closest_coop), which counts the same way)
 for scene_id, strategy, spp in ((3, "mis", 1024), (10, "mis", 4096), (8, "mis", 1024), (17, "nee", 16384)):
     W, H = 1920, 1080
     sc = prod.new_scene()
@@ -24,7 +25,8 @@ for scene_id, strategy, spp in ((3, "mis", 1024), (10, "mis", 4096), (8, "mis", 
     st = pkg.ffi.Stats()
     prod.render_accum_device(sc, cam, pkg.make_params(spp, strategy, "sobol", collect_stats=2), 0, 16, d.value, None, stats=st)
     s = st.as_dict()
-    ties, rays = s["phase_cycles"][9], s["closest_rays"]
+    ties, differ, rays = s["phase_cycles"][9] & 0xffffffff, s["phase_cycles"][9] >> 32, s["closest_rays"]
     print(json.dumps({"scene": scene_id, "strategy": strategy, "closest_rays": rays, "exact_t_ties": ties, "ties_per_ray": ties / max(rays, 1),
+                      "ties_between_different_material_or_normal": differ,
                       "closest_hits": s["closest_hits"]}))
     hip.hipFree(d)

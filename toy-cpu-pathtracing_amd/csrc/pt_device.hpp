@@ -385,7 +385,8 @@ struct StatCounters {
     uint32_t w[8];      // wave-level step counts (incremented by the first active lane only), mi355pt_stats.wave_steps
     uint32_t hist[16];  // mi355pt_stats.busy_hist (wave leader only)
     uint32_t dv[4];     // mi355pt_stats.divergence (lane 0 only)
-    uint32_t ties;      // closest-hit merges that met an EXACT tie in t with another triangle (mi355pt_stats.phase_cycles[9])
+    uint32_t ties;      // closest-hit merges that met an EXACT tie in t with another triangle (mi355pt_stats.phase_cycles[9], low 32 bits)
+    uint32_t ties_differ;   // ... between triangles of different material or geometric normal: the ties whose winner can matter (high 32 bits)
 };
 PT_DEV bool wave_leader() { return __builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u; }
 // number of set bits of a wave mask below this lane (v_mbcnt: no lane-mask registers to keep, two instructions)
@@ -944,8 +945,18 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
             TriVerts tv = load_tri(sc.tris, tri);
             float t, b0, b1, b2;
             if (STATS) { st.tris_closest++; if (wave_leader()) st.w[1]++; }
-            if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, t_lim, tv, t, b0, b1, b2))
+            if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, t_lim, tv, t, b0, b1, b2)) {
+                if (STATS) {    // exact ties in t (see trace_pair_coop)
+                    const unsigned long long cur = L.best[own];
+                    if ((uint32_t)(cur >> 32) == __float_as_uint(t) && (uint32_t)cur != tri) {
+                        st.ties++;
+                        const float4* sa = (const float4*)(sc.shade + tri); const float4* sb = (const float4*)(sc.shade + (uint32_t)cur);
+                        const float4 ga = sa[6], gb = sb[6];
+                        if (sa[4].z != sb[4].z || ga.x != gb.x || ga.y != gb.y || ga.z != gb.z) st.ties_differ++;
+                    }
+                }
                 atomicMin(&L.best[own], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)tri);
+            }
         }
         head += n;
         __syncthreads();
@@ -1180,7 +1191,12 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
                 else {
                     if (STATS) {    // the merge keeps the LOWER triangle index on an exact tie, the reference the second child / earlier leaf item (bvh.rs:381-388): how often does it matter?
                         const unsigned long long cur = L.best[own];
-                        if ((uint32_t)(cur >> 32) == __float_as_uint(t) && (uint32_t)cur != tri) st.ties++;
+                        if ((uint32_t)(cur >> 32) == __float_as_uint(t) && (uint32_t)cur != tri) {
+                            st.ties++;
+                            const float4* sa = (const float4*)(sc.shade + tri); const float4* sb = (const float4*)(sc.shade + (uint32_t)cur);
+                            const float4 ga = sa[6], gb = sb[6];
+                            if (sa[4].z != sb[4].z || ga.x != gb.x || ga.y != gb.y || ga.z != gb.z) st.ties_differ++;
+                        }
                     }
                     atomicMin(&L.best[own], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)tri);
                 }

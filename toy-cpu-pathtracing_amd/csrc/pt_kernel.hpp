@@ -49,7 +49,7 @@ PT_DEV void flush_stats(DevStats* stats, const StatCounters& st) {
     for (int i = 0; i < 8; ++i) if (st.w[i]) atomicAdd(&stats->wave_steps[i], (unsigned long long)st.w[i]);
     for (int i = 0; i < 16; ++i) if (st.hist[i]) atomicAdd(&stats->busy_hist[i >> 3][i & 7], (unsigned long long)st.hist[i]);
     for (int i = 0; i < 4; ++i) if (st.dv[i]) atomicAdd(&stats->divergence[i], (unsigned long long)st.dv[i]);
-    if (st.ties) atomicAdd(&stats->phase_cycles[9], (unsigned long long)st.ties);
+    if (st.ties) atomicAdd(&stats->phase_cycles[9], (unsigned long long)st.ties | ((unsigned long long)st.ties_differ << 32));
 }
 
 #ifndef PT_ANY_DEFERRED
