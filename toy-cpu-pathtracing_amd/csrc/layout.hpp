@@ -55,12 +55,17 @@ static_assert(sizeof(DevNode4) == 128, "wide node must be 128 B");
 // PT_NODE_FMA 1: the slab distances of the 4-wide step are ONE fma per plane, plane * (1/d) + (-(o * (1/d))), instead of a subtraction and a
 // multiplication ((plane - o) * (1/d)).  The fma form cancels: its absolute error is u * |o / d| + u * |t| (u = 2^-24), i.e. up to 2 u * max(|o|, |plane|)
 // measured in space, where the two-step form has 2 u * |t|.  The host therefore pads every box of the DevNode4 tree by NODE4_PAD_REL x the largest
-// coordinate magnitude of the scene (16 x that bound) when it uploads the tree (scene.cpp): the padded test can only visit MORE nodes than the
+// coordinate magnitude of the scene (2 x that bound) when it uploads the tree (scene.cpp): the padded test can only visit MORE nodes than the
 // exact one, and which triangle a ray hits is decided by the unchanged watertight triangle test.  The BVH2 records (probes, canonical counts) stay exact.
 #ifndef PT_NODE_FMA
-#define PT_NODE_FMA 0
+#define PT_NODE_FMA 1        // measured (round 3, same box): pad 2^-20 +0.1...0.25 %, pad 2^-22 +0.55...0.75 % (scenes 3 / 8 / 10)
 #endif
-constexpr float NODE4_PAD_REL = 9.5367431640625e-07f;   // 2^-20
+#ifndef PT_NODE_PAD_LOG2
+#define PT_NODE_PAD_LOG2 22
+#endif
+constexpr float NODE4_PAD_REL = 1.0f / (float)(1u << PT_NODE_PAD_LOG2);   // 2^-22 = twice the error bound 2^-23 x R.  The pad must stay well below RAY_EPS (1e-5): 2^-20 of the
+                                                                         // 12-unit Cornell room is 1.1e-5, and the flat leaf boxes of the walls then contain the origins of the rays
+                                                                         // that leave them (every bounce tests the wall's own triangles again)
 // PT_NODE_Q16 1: the cooperative traversals read a 64-BYTE node — the four child boxes as 16-bit planes on ONE grid over the scene's
 // bounds (lo planes snapped down, hi planes up, so a quantised box contains its box), 4 x dwordx4 per lane and node step instead of 7;
 // dequantisation is free (t = q * (cell / d) + (origin - o) / d: one fma on the converted integer, SDWA word select in the conversion).
