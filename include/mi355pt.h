@@ -41,7 +41,13 @@ enum {
     MI355PT_SPEC_LUT470 = 2,              /* DenselySampledSpectrum, id from add_lut470 (presets::cie_illum_d6500(), glass_sf11_eta(), ...) */
     MI355PT_SPEC_TEXTURE_ALBEDO_SRGB = 3, /* SpectrumParameter::texture(RgbTexture::load_srgb, SpectrumType::Albedo), id from add_tex_rgb8 */
     MI355PT_SPEC_SIGMOID = 4,             /* explicit sigmoid-polynomial coefficients c0,c1,c2 (rgb_sigmoid_polynomial.rs:179-182) */
-    MI355PT_SPEC_RGB_ALBEDO_SRGB_LINEAR = 5 /* RgbAlbedoSpectrum<ColorSrgbLinear>::new(c): the same table, no EOTF inversion */
+    MI355PT_SPEC_RGB_ALBEDO_SRGB_LINEAR = 5, /* RgbAlbedoSpectrum<ColorSrgbLinear>::new(c): the same table, no EOTF inversion */
+    /* SpectrumParameter::texture(RgbTexture::load_srgb, SpectrumType::Illuminant / Unbounded) (texture/rgb_texture.rs:56-64): per lookup
+     * scale = 2 max(rgb), the sigmoid of rgb / scale, times scale — and for Illuminant times presets::cie_illum_d6500(), whose LUT470 id
+     * goes in c[0] (as a number).  id = texture from add_tex_rgb8.  Accepted for the radiance of EMISSIVE materials (what the types are for;
+     * rgb_illuminant_spectrum.rs:26-46, rgb_unbounded_spectrum.rs:23-42); a black texel gives 0 where the reference divides 0 / 0. */
+    MI355PT_SPEC_TEXTURE_ILLUMINANT_SRGB = 6,
+    MI355PT_SPEC_TEXTURE_UNBOUNDED_SRGB = 7
 };
 typedef struct mi355pt_spectrum {
     uint32_t kind;
@@ -81,6 +87,8 @@ typedef struct mi355pt_material_desc {
      * rule, texture/sampler.rs:81-107), MI355PT_NONE = the constant above.  material/parameter.rs:58-83 */
     uint32_t metallic_tex, roughness_tex;   /* roughness_tex also on glass / plastic (glass_material.rs:42,116, plastic_material.rs:43,104) */
     uint32_t clearcoat_thickness_tex;   /* clearcoat only (scene_18.rs:37-42) */
+    uint32_t intensity_tex;             /* emissive only: FloatParameter::texture intensity (emissive_material.rs:55-56: sampled at the hit /
+                                         * sampled point; the light-pick weight takes it at uv (0.5, 0.5), :69-76); MI355PT_NONE = `intensity` */
 } mi355pt_material_desc;
 
 /* ---- delta lights: CreatePrimitiveDesc::{PointLightPrimitive, SpotLightPrimitive, DirectionalLightPrimitive}

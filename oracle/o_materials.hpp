@@ -454,7 +454,7 @@ struct MaterialEval {
     // EmissiveMaterial::radiance (emissive_material.rs:48-60)
     SS emissive_radiance(const Material& m, const Wavelengths& wl, V2 uv) const {
         SS rad = scene.sample_spectrum_param(m.color, uv, wl, ctr);
-        return rad * m.intensity;
+        return rad * scene.sample_float_param(m.intensity, m.intensity_tex, uv);        // FloatParameter intensity (:55-56)
     }
 };
 

@@ -11,11 +11,12 @@
 namespace oracle {
 
 // ---------------- parameters / materials (material/parameter.rs) ----------------
-enum SpectrumParamKind : uint32_t { SP_CONSTANT = 0, SP_TEXTURE_ALBEDO_SRGB = 1 };
+enum SpectrumParamKind : uint32_t { SP_CONSTANT = 0, SP_TEXTURE_ALBEDO_SRGB = 1, SP_TEXTURE_ILLUMINANT_SRGB = 2, SP_TEXTURE_UNBOUNDED_SRGB = 3 };
 struct SpectrumParameter {
     uint32_t kind = SP_CONSTANT;
     Spectrum constant;
     int texture = -1;
+    const float* illuminant = nullptr;     // SP_TEXTURE_ILLUMINANT_SRGB: presets::cie_illum_d6500() (470 entries)
 };
 
 enum MaterialType : uint32_t { MAT_LAMBERT = 0, MAT_EMISSIVE = 1, MAT_GLASS = 2, MAT_PLASTIC = 3, MAT_CLEARCOAT = 4, MAT_METAL = 5 };
@@ -29,6 +30,7 @@ struct Material {
     Spectrum eta;                  // Glass: LUT spectrum; Plastic: constant; Metal: real part of the index
     Spectrum k;                    // Metal: extinction coefficient (presets::au_k() ...)
     int metallic_tex = -1, roughness_tex = -1, cc_thickness_tex = -1;   // FloatParameter::Texture (grey image in the red channel), -1 = constant
+    int intensity_tex = -1;        // emissive: FloatParameter::Texture intensity (emissive_material.rs:55-56,69-76)
     bool thin = false;
     float roughness = 0.0f;
     // clearcoat (simple_pbr_clearcoat_material.rs): filled by the API when type == MAT_CLEARCOAT
@@ -457,9 +459,26 @@ struct Scene {
         if (c) c->textured_lookups++;
         float rgb[3];
         bilinear_sample_rgb(textures[sp.texture], uv, rgb);
+        if (sp.kind == SP_TEXTURE_ALBEDO_SRGB) {
+            Spectrum s; s.kind = SPEC_SIGMOID;
+            table.get_srgb_encoded(rgb, s.c);
+            return s.sample(w);
+        }
+        // SpectrumType::{Illuminant, Unbounded} (texture/rgb_texture.rs:56-64): RgbIlluminantSpectrum::new / RgbUnboundedSpectrum::new of the texel
+        // (rgb_illuminant_spectrum.rs:26-46, rgb_unbounded_spectrum.rs:23-42): scale = 2 max(rgb), the sigmoid of rgb / scale
+        float mx = std::fmax(rgb[0], std::fmax(rgb[1], rgb[2]));
+        float scale = 2.0f * mx;
+        if (scale == 0.0f) return SS::zero();                                // black texel: 0 instead of the reference's 0 / 0
+        float scaled[3] = {rgb[0] / scale, rgb[1] / scale, rgb[2] / scale};
         Spectrum s; s.kind = SPEC_SIGMOID;
-        table.get_srgb_encoded(rgb, s.c);
-        return s.sample(w);
+        table.get_srgb_encoded(scaled, s.c);
+        SS out = SS::zero();
+        for (int i = 0; i < 4; ++i) {
+            if (i > 0 && w.is_secondary_terminated()) break;
+            float v = s.value(w.lambda[i]);
+            out.v[i] = sp.kind == SP_TEXTURE_ILLUMINANT_SRGB ? (scale * v) * Spectrum::lut_value(sp.illuminant, w.lambda[i]) : scale * v;
+        }
+        return out;
     }
 
     // FloatParameter::sample (parameter.rs:65-72) -> FloatTexture::sample, gamma_corrected = false (float_texture.rs:33-52)
@@ -488,7 +507,7 @@ struct Scene {
         const Primitive& p = primitives[prim];
         const Material& m = materials[p.material];
         SS rad = sample_spectrum_param(m.color, V2{0.5f, 0.5f}, w, nullptr);
-        return (rad * m.intensity) * p.area_sum;
+        return (rad * sample_float_param(m.intensity, m.intensity_tex, V2{0.5f, 0.5f})) * p.area_sum;   // average_intensity: textures at the centre (:63-79)
     }
 };
 

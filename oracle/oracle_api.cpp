@@ -46,6 +46,14 @@ static bool lower_param(ptoracle_scene* h, const mi355pt_spectrum& in, SpectrumP
         if (in.id >= h->scene.textures.size() || !h->scene.table.valid()) return false;
         out->kind = SP_TEXTURE_ALBEDO_SRGB; out->texture = (int)in.id; return true;
     }
+    if (in.kind == MI355PT_SPEC_TEXTURE_ILLUMINANT_SRGB || in.kind == MI355PT_SPEC_TEXTURE_UNBOUNDED_SRGB) {
+        if (in.id >= h->scene.textures.size() || !h->scene.table.valid()) return false;
+        out->texture = (int)in.id;
+        if (in.kind == MI355PT_SPEC_TEXTURE_UNBOUNDED_SRGB) { out->kind = SP_TEXTURE_UNBOUNDED_SRGB; return true; }
+        const uint32_t lut = (uint32_t)in.c[0];
+        if (!(in.c[0] >= 0.0f) || lut >= h->scene.luts.size()) return false;
+        out->kind = SP_TEXTURE_ILLUMINANT_SRGB; out->illuminant = h->scene.luts[lut].data(); return true;
+    }
     out->kind = SP_CONSTANT;
     return lower_spectrum(h, in, &out->constant);
 }
@@ -109,6 +117,8 @@ int ptoracle_scene_add_material(ptoracle_scene* s, const mi355pt_material_desc* 
     if (m.normal_tex >= (int)s->scene.textures.size()) return -1;
     m.normal_flip_y = d->normal_flip_y != 0;
     m.intensity = d->intensity;
+    m.intensity_tex = (d->type != MI355PT_MAT_EMISSIVE || d->intensity_tex == MI355PT_NONE) ? -1 : (int)d->intensity_tex;
+    if (m.intensity_tex >= (int)s->scene.textures.size()) return -1;
     if (d->type == MI355PT_MAT_GLASS || d->type == MI355PT_MAT_PLASTIC) { if (!lower_spectrum(s, d->eta, &m.eta)) return -1; }
     m.thin = d->thin != 0; m.roughness = d->roughness;
     m.metallic_tex = d->metallic_tex == MI355PT_NONE ? -1 : (int)d->metallic_tex;

@@ -152,7 +152,8 @@ KNIFE_EDGE_SCENES = (9, 13, 19)   # solid constant-eta plastic: compared with th
                                                (12, "mis"), (13, "mis"), (14, "nee"), (15, "mis"), (16, "mis"), (17, "nee"), (17, "mis"), (18, "nee"),
                                                (19, "mis"), (19, "pt"), (19, "nee"), (20, "mis"), (20, "pt"), (21, "mis"), (21, "nee"), (22, "mis"),
                                                (22, "nee"), (27, "mis"), (27, "nee"), (27, "pt"),
-                                               (29, "pt"), (29, "nee"), (29, "mis"), (30, "pt"), (30, "nee"), (30, "mis")])
+                                               (29, "pt"), (29, "nee"), (29, "mis"), (30, "pt"), (30, "nee"), (30, "mis"),
+                                               (31, "pt"), (31, "nee"), (31, "mis"), (32, "nee"), (32, "mis")])
 def test_frames_match_the_oracle_sample_for_sample(product, oracle, pkg, scene_id, strategy):
     """Every scene id of the radiance test, through the scene's own kernel specialisation (= what bench.py runs for it).  Outside rough
     refraction nothing amplifies a last-bit difference, so GPU and oracle must trace the SAME paths for all but a handful of samples:
@@ -253,12 +254,14 @@ def test_gpu_pt_nee_mis_consistency(product, pkg, scene_id):
     assert gamma22_rmse_u8(imgs["pt"], imgs["mis"]) <= 0.013
 
 
-def test_gpu_pt_nee_mis_consistency_textured_emitter(product, pkg):
-    """The reference's estimator-consistency criterion on the textured emitter of scene 30: PT sees the panel's radiance at the HIT uv, NEE
+@pytest.mark.parametrize("scene_id", [30, 31])
+def test_gpu_pt_nee_mis_consistency_textured_emitter(product, pkg, scene_id):
+    """The reference's estimator-consistency criterion on the textured emitters: PT sees the panel's radiance at the HIT uv, NEE
     and MIS sample a point on it and look the radiance up THERE, weighting the light by its value at uv (0.5, 0.5) — three code paths
-    that must converge to one picture."""
+    that must converge to one picture.  Scene 30: Albedo-type radiance texture, constant intensity; scene 31: Illuminant-type texture
+    (RgbIlluminantSpectrum per texel, rgb_texture.rs:56-64) times a FloatParameter::texture intensity ramp (emissive_material.rs:55-56)."""
     sc = product.new_scene()
-    cam = pkg.scenes.load_scene(sc, 30, 200, 150, tex_size=256)
+    cam = pkg.scenes.load_scene(sc, scene_id, 200, 150, tex_size=256)
     # (32768 spp: unidirectional PT finds the 1.8 x 1.8 panel by chance only; 0.0146 at 8192 spp is its noise — the oracle's LINEAR channel
     # means of the three strategies agree within 1 %)
     imgs = {s: median3(product.quantize_u8(product.render(sc, cam, pkg.make_params(32768, s, "random")))) for s in ("pt", "nee", "mis")}

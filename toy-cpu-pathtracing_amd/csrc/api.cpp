@@ -305,6 +305,22 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
     m.intensity = d->intensity; m.roughness = d->roughness; m.metallic = d->metallic; m.ior = d->ior;
     m.cc_ior = d->clearcoat_ior; m.cc_roughness = d->clearcoat_roughness; m.cc_thickness = d->clearcoat_thickness;
     m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu;
+    m.intensity_avg = d->intensity;
+    if (d->type == MI355PT_MAT_EMISSIVE && d->intensity_tex != MI355PT_NONE) {
+        // FloatParameter::texture intensity (emissive_material.rs:55-56,69-76): the device reads it at the hit / sampled uv through the
+        // material's metallic_tex slot; the light-pick weight uses ONE value, the texture at uv (0.5, 0.5), computed here with the device's
+        // bilinear arithmetic (texture/sampler.rs:81-107: red channel of the gamma-encoded texel / 255)
+        if (d->intensity_tex >= im.textures.size()) return fail(MI355PT_E_INVALID, "bad intensity texture id");
+        m.metallic_tex = d->intensity_tex;
+        const SceneImpl::Tex& t = im.textures[d->intensity_tex];
+        const float u = std::fabs(0.5f - std::trunc(0.5f)), v = 1.0f - std::fabs(0.5f - std::trunc(0.5f));
+        const float x = u * ((float)t.w - 1.0f), y = v * ((float)t.h - 1.0f);
+        const uint32_t x0 = (uint32_t)std::floor(x), y0 = (uint32_t)std::floor(y), x1 = std::min(x0 + 1u, t.w - 1u), y1 = std::min(y0 + 1u, t.h - 1u);
+        const float fx = x - (float)x0, fy = y - (float)y0;
+        auto red = [&](uint32_t xx, uint32_t yy) { return (float)t.rgb[((size_t)yy * t.w + xx) * 3] / 255.0f; };
+        const float top = red(x0, y0) * (1.0f - fx) + red(x1, y0) * fx, bottom = red(x0, y1) * (1.0f - fx) + red(x1, y1) * fx;
+        m.intensity_avg = top * (1.0f - fy) + bottom * fy;
+    }
     if (d->type == MI355PT_MAT_CLEARCOAT && d->clearcoat_thickness_tex != MI355PT_NONE) {
         if (d->clearcoat_thickness_tex >= im.textures.size()) return fail(MI355PT_E_INVALID, "bad clearcoat thickness texture id");
         m.cc_thickness_tex = d->clearcoat_thickness_tex;
@@ -324,8 +340,8 @@ int mi355pt_scene_add_material(mi355pt_scene* s, const mi355pt_material_desc* d,
             if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, err);
             break;
         case MI355PT_MAT_EMISSIVE:
-            // SpectrumParameter::Texture radiance (emissive_material.rs:48-79): Albedo-type sRGB texture, looked up at the hit / sampled uv
-            if ((rc = im.lower_spectrum(d->color, &m.color, true, &err))) return fail(rc, "emissive radiance: " + err);
+            // SpectrumParameter::Texture radiance (emissive_material.rs:48-79): an sRGB texture of any SpectrumType, looked up at the hit / sampled uv
+            if ((rc = im.lower_spectrum(d->color, &m.color, 2, &err))) return fail(rc, "emissive radiance: " + err);
             break;
         case MI355PT_MAT_GLASS:
         case MI355PT_MAT_PLASTIC:
@@ -360,10 +376,10 @@ int mi355pt_scene_add_delta_light(mi355pt_scene* s, const mi355pt_light_desc* d)
     DevMaterial m{};                        // hidden emissive material: carries the light's spectrum with intensity 1
     std::string err;
     int rc;
-    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu; m.intensity = 1.0f;
+    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu; m.intensity = 1.0f; m.intensity_avg = 1.0f;
     if ((rc = im.lower_spectrum(d->spectrum, &m.color, false, &err))) return fail(rc, "light spectrum: " + err);
     im.materials.push_back(m);
-    mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.color = d->spectrum; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE;
+    mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.color = d->spectrum; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE; md.intensity_tex = MI355PT_NONE;
     im.mat_descs.push_back(md);
     HostDeltaLight hl{*d, (uint32_t)im.materials.size() - 1, (uint32_t)im.instances.size()};
     im.delta_lights.push_back(hl);
@@ -380,9 +396,9 @@ int mi355pt_scene_add_environment_light(mi355pt_scene* s, float intensity, const
     std::memcpy(he.l2w, l2w, sizeof(float) * 16);
     im.envs.push_back(std::move(he));
     DevMaterial m{};                         // hidden emissive material: the integrated RgbIlluminantSpectrum, filled in at build()
-    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu; m.intensity = 1.0f; m.color.kind = SPK_CONSTANT;
+    m.type = MT_EMISSIVE; m.normal_tex = 0xffffffffu; m.metallic_tex = m.roughness_tex = m.cc_thickness_tex = 0xffffffffu; m.intensity = 1.0f; m.intensity_avg = 1.0f; m.color.kind = SPK_CONSTANT;
     im.materials.push_back(m);
-    mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE;
+    mi355pt_material_desc md{}; md.type = MI355PT_MAT_EMISSIVE; md.intensity = 1.0f; md.normal_tex = MI355PT_NONE; md.intensity_tex = MI355PT_NONE;
     im.mat_descs.push_back(md);
     mi355pt_light_desc ld{}; ld.kind = LK_ENV; ld.intensity = intensity; std::memcpy(ld.local_to_world, l2w, sizeof(float) * 16);
     im.delta_lights.push_back(HostDeltaLight{ld, (uint32_t)im.materials.size() - 1, (uint32_t)im.instances.size(), (uint32_t)im.envs.size() - 1});

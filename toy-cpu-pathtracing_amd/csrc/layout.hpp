@@ -128,7 +128,8 @@ struct DevTexture {
 struct DevSpectrum {
     uint32_t kind;
     uint32_t id;       // LUT index or texture index
-    float c[3];        // constant in c[0] or sigmoid coefficients
+    float c[3];        // constant in c[0] or sigmoid coefficients; SPK_TEXTURE: c[0] = SpectrumType of the texture as bits (0 Albedo, 1 Illuminant,
+                       // 2 Unbounded: rgb_texture.rs:56-64), c[1] = the illuminant's LUT id as bits (Illuminant)
     uint32_t pad[3];   // SPK_ILLUM: pad[0] = the scale (float bits); SPK_TEXTURE: the texture's DevTexture {offset, w, h}, so that a lookup
                        // does not wait for a descriptor fetch between the material record and the texels
 };
@@ -141,11 +142,14 @@ struct alignas(16) DevMaterial {
     uint32_t normal_flip_y;
     uint32_t thin;
     float intensity, roughness, metallic, ior;
-    float cc_ior, cc_roughness, cc_thickness, pad0;
+    float cc_ior, cc_roughness, cc_thickness;
+    float intensity_avg;   // emissive: what EmissiveMaterial::average_intensity multiplies with (emissive_material.rs:69-76): `intensity`, or the
+                           // intensity texture at uv (0.5, 0.5), sampled once by the host with the device's bilinear arithmetic
     DevSpectrum color;
     DevSpectrum eta;       // glass: LUT, plastic: constant
     DevSpectrum cc_tint;   // clearcoat tint; metal: extinction coefficient k
-    uint32_t metallic_tex, roughness_tex;   // FloatParameter::Texture ids (red channel), ~0 = use the constants above
+    uint32_t metallic_tex, roughness_tex;   // FloatParameter::Texture ids (red channel), ~0 = use the constants above; EMISSIVE materials:
+                                            // metallic_tex is the INTENSITY texture (mi355pt_material_desc::intensity_tex)
     uint32_t cc_thickness_tex;
     uint32_t cc_albedo_lut;   // clearcoat: first entry of this material's 64-entry coat-albedo table in DevScene::cc_albedo
     DevTexture normal_desc;   // textures[normal_tex], embedded for the same reason as DevSpectrum::pad

@@ -393,15 +393,27 @@ PT_DEV bool wave_leader() { return __builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_re
 PT_DEV uint32_t rank_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 // SpectrumParameter::sample(uv).sample(lambda)  (parameter.rs:38-47, spectrum.rs:32-46)
-template <bool STATS, bool TEX = true>
+// XT: the texture may be of SpectrumType Illuminant / Unbounded (emitters: the callers that pass TEX = FEAT_EMTEX)
+template <bool STATS, bool TEX = true, bool XT = false>
 PT_DEV void eval_spectrum(const DevScene& sc, const DevSpectrum& sp, const Wl& w, f2 uv, float out[4], StatCounters& st) {
     if (STATS) st.spectrum_evals++;
     float c0 = sp.c[0], c1 = sp.c[1], c2 = sp.c[2];
     uint32_t kind = sp.kind;
+    float tex_scale = 1.0f; uint32_t tex_sub = 0u, tex_lut = 0u;
     if (TEX && kind == SPK_TEXTURE) {
         if (STATS) st.textured_lookups++;
         float rgb[3], c[3];
         bilinear_rgb(sc, DevTexture{sp.pad[0], sp.pad[1], sp.pad[2], 0u}, uv, rgb);
+        if (XT) {
+            // SpectrumType::{Illuminant, Unbounded} textures (rgb_texture.rs:56-64 -> rgb_illuminant_spectrum.rs:26-46, rgb_unbounded_spectrum.rs:23-42):
+            // the sigmoid of rgb / (2 max rgb), times that scale (and the illuminant)
+            tex_sub = __float_as_uint(sp.c[0]); tex_lut = __float_as_uint(sp.c[1]);
+            if (tex_sub != 0u) {
+                tex_scale = 2.0f * fmaxf(rgb[0], fmaxf(rgb[1], rgb[2]));
+                if (tex_scale == 0.0f) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }      // black texel: 0 (the reference divides 0 / 0)
+                rgb[0] = rgb[0] / tex_scale; rgb[1] = rgb[1] / tex_scale; rgb[2] = rgb[2] / tex_scale;
+            }
+        }
         rgb2spec_lookup(sc, rgb, c);
         c0 = c[0]; c1 = c[1]; c2 = c[2];
         kind = SPK_SIGMOID;
@@ -416,6 +428,7 @@ PT_DEV void eval_spectrum(const DevScene& sc, const DevSpectrum& sp, const Wl& w
         else if (kind == SPK_SIGMOID) v = sigmoid_value(c0, c1, c2, lam[i]);
         else if (kind == SPK_ILLUM) v = __uint_as_float(sp.pad[0]) * sigmoid_value(c0, c1, c2, lam[i]) * lut_value(lut, lam[i]);   // rgb_illuminant_spectrum.rs:44-46
         else v = lut_value(lut, lam[i]);
+        if (XT && tex_sub != 0u) v = tex_sub == 1u ? (tex_scale * v) * lut_value(sc.luts + (size_t)tex_lut * 470, lam[i]) : tex_scale * v;
         out[i] = (i > 0 && w.term) ? 0.0f : v;
     }
 }

@@ -317,10 +317,10 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity_avg) * lt.area_sum;
                         inf_sum += sum / 4.0f;
                     }
                     for (uint32_t li = 0; li < sc.n_lights; ++li) {
@@ -329,10 +329,10 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity_avg) * lt.area_sum;
                         const float probability = inf_sum == 0.0f ? 0.0f : (sum / 4.0f) / inf_sum;
                         light_pdf += probability * env_pdf(sc.envs[lt.first_tri], rd);
                     }
@@ -351,8 +351,9 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
         float Le[4] = {0, 0, 0, 0};
         if (emissive) {                                                      // evaluate_emissive_surface :54-73
             DevSpectrum rs = load_spectrum(&mat->color);
-            eval_spectrum<STATS, (FEAT & FEAT_EMTEX) != 0>(sc, rs, wl, sf.uv, Le, st);
+            eval_spectrum<STATS, (FEAT & FEAT_EMTEX) != 0, (FEAT & FEAT_EMTEX) != 0>(sc, rs, wl, sf.uv, Le, st);
             float inten = mat->intensity;
+            if ((FEAT & FEAT_EMTEX) && mat->metallic_tex != 0xffffffffu) { float t3[3]; bilinear_rgb(sc, mat->metallic_tex, sf.uv, t3); inten = t3[0]; }   // FloatParameter::texture intensity at the hit (emissive_material.rs:55-56)
 #pragma unroll
             for (int i = 0; i < 4; ++i) Le[i] = Le[i] * inten;
         }
@@ -375,12 +376,12 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         // texture, whose phi is taken at uv (0.5, 0.5) (EmissiveMaterial::average_intensity, emissive_material.rs:61-79)
                         float sum = 0.0f;
                         float area = sc.lights[0].area_sum;
-                        if ((FEAT & FEAT_EMTEX) && mat->color.kind == SPK_TEXTURE) {
+                        if ((FEAT & FEAT_EMTEX) && (mat->color.kind == SPK_TEXTURE || mat->metallic_tex != 0xffffffffu)) {
                             float ph[4];
                             DevSpectrum ls = load_spectrum(&mat->color);
-                            eval_spectrum<false, true>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                            eval_spectrum<false, true, true>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) sum += (ph[i] * mat->intensity) * area;
+                            for (int i = 0; i < 4; ++i) sum += (ph[i] * mat->intensity_avg) * area;
                         } else {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) sum += Le[i] * area;
@@ -392,8 +393,8 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
-                        float inten = lm->intensity;
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        float inten = lm->intensity_avg;
                         float sum = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += (ph[i] * inten) * lt.area_sum;
@@ -827,8 +828,8 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     const DevMaterial* lm0 = sc.materials + sc.lights[0].material;
                     DevSpectrum ls0 = load_spectrum(&lm0->color);
                     // (a textured radiance: phi at uv (0.5, 0.5), emissive_material.rs:61-79; the radiance itself follows at the sampled point)
-                    eval_spectrum<STATS, (FEAT & FEAT_EMTEX) != 0>(sc, ls0, wl, f2{0.5f, 0.5f}, lrad, st);
-                    float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity;
+                    eval_spectrum<STATS, (FEAT & FEAT_EMTEX) != 0, (FEAT & FEAT_EMTEX) != 0>(sc, ls0, wl, f2{0.5f, 0.5f}, lrad, st);
+                    float sum = 0.0f, area = sc.lights[0].area_sum, inten = lm0->intensity_avg;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sum += (lrad[i] * inten) * area;
                     wsum = wpick = sum / 4.0f;
@@ -838,10 +839,10 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity_avg) * lt.area_sum;
                         wsum += sum / 4.0f;
                     }
                     float cum = 0.0f; bool chosen = false;
@@ -851,10 +852,10 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         const DevMaterial* lm = sc.materials + lt.material;
                         float ph[4];
                         DevSpectrum ls = load_spectrum(&lm->color);
-                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
+                        eval_spectrum<false, (FEAT & FEAT_EMTEX) != 0, (FEAT & FEAT_EMTEX) != 0>(sc, ls, wl, f2{0.5f, 0.5f}, ph, st);
                         float sum = 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity) * lt.area_sum;
+                        for (int i = 0; i < 4; ++i) sum += (ph[i] * lm->intensity_avg) * lt.area_sum;
                         float wt = sum / 4.0f;
                         cum += wt;
                         if (!chosen && (ul < cum / wsum || li == sc.n_lights - 1)) {
@@ -873,6 +874,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     f3 dv, wi_r, ln = mk3(0, 0, 1);
                     float pdf_a = 1.0f, pdf_dir = 0.0f;
                     float dl_scale = 1.0f;                                      // delta lights: falloff
+                    float l_inten = lm->intensity;                              // area lights: the emitter's intensity at the sampled point
                     float env_rad[4] = {0, 0, 0, 0};
                     if ((FEAT & FEAT_ENV) && lt.kind == LK_ENV) {               // sample_infinite_light (environment_light.rs:317-340)
                         const DevEnv& e = sc.envs[lt.first_tri];
@@ -907,11 +909,14 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     if (luv.x < luv.y) { b0 = luv.x / 2.0f; b1 = luv.y - b0; } else { b1 = luv.y / 2.0f; b0 = luv.x - b1; }
                     float b2 = 1.0f - b0 - b1;
                     f3 lp = p0 * b0 + p1 * b1 + p2 * b2;
-                    if ((FEAT & FEAT_EMTEX) && lm->color.kind == SPK_TEXTURE) {    // EmissiveMaterial::radiance at the sampled point's uv (:48-59, emissive_triangle_mesh.rs:237-247)
+                    if ((FEAT & FEAT_EMTEX) && (lm->color.kind == SPK_TEXTURE || lm->metallic_tex != 0xffffffffu)) {    // EmissiveMaterial::radiance at the sampled point's uv (:48-59, emissive_triangle_mesh.rs:237-247)
                         const float* tu = sc.light_uvs + (size_t)(lt.first_tri + tsel) * 6;
                         const f2 suv = f2{tu[0] * b0 + tu[2] * b1 + tu[4] * b2, tu[1] * b0 + tu[3] * b1 + tu[5] * b2};
-                        DevSpectrum lsx = load_spectrum(&lm->color);
-                        eval_spectrum<STATS, true>(sc, lsx, wl, suv, lrad, st);
+                        if (lm->color.kind == SPK_TEXTURE) {
+                            DevSpectrum lsx = load_spectrum(&lm->color);
+                            eval_spectrum<STATS, true, true>(sc, lsx, wl, suv, lrad, st);
+                        }
+                        if (lm->metallic_tex != 0xffffffffu) { float t3[3]; bilinear_rgb(sc, lm->metallic_tex, suv, t3); l_inten = t3[0]; }   // its intensity texture there
                     }
                     ln = mk3(qc.z, qc.w, qd.x);                                  // normalize(normalize(cross(p1 - p0, p2 - p0))), precomputed
                     pdf_a = 1.0f / lt.area_sum;
@@ -1039,7 +1044,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     const float rden = 1.0f / (pdf_a * lprob);   // one division for the four wavelengths (<= 1 ulp from x / (pdf_a * lprob))
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        sh_c[i] = (T[i] * (((fl[i] * (lrad[i] * lm->intensity)) * g) * rden)) * wgt;
+                        sh_c[i] = (T[i] * (((fl[i] * (lrad[i] * l_inten)) * g) * rden)) * wgt;
                     }
                 }
             }

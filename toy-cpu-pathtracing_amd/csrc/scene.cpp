@@ -155,7 +155,7 @@ void coat_albedo_table(float alpha_f, float r0_f, float out[64]) {
     }
 }
 
-int SceneImpl::lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, bool allow_texture, std::string* err) const {
+int SceneImpl::lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, int allow_texture, std::string* err) const {
     std::memset(out, 0, sizeof(*out));
     switch (in.kind) {
         case MI355PT_SPEC_CONSTANT: out->kind = SPK_CONSTANT; out->c[0] = in.c[0]; return MI355PT_OK;
@@ -173,6 +173,17 @@ int SceneImpl::lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, bool
             if (!allow_texture) { *err = "texture spectrum not supported for this parameter"; return MI355PT_E_INVALID; }
             if (in.id >= textures.size() || table.empty()) { *err = "bad texture id or missing rgb2spec table"; return MI355PT_E_INVALID; }
             out->kind = SPK_TEXTURE; out->id = in.id; return MI355PT_OK;
+        case MI355PT_SPEC_TEXTURE_ILLUMINANT_SRGB:
+        case MI355PT_SPEC_TEXTURE_UNBOUNDED_SRGB: {
+            // SpectrumType::{Illuminant, Unbounded} (rgb_texture.rs:56-64): the emitters' types
+            if (allow_texture < 2) { *err = "Illuminant / Unbounded texture spectra are accepted for emitter radiance only"; return MI355PT_E_INVALID; }
+            if (in.id >= textures.size() || table.empty()) { *err = "bad texture id or missing rgb2spec table"; return MI355PT_E_INVALID; }
+            const uint32_t sub = in.kind == MI355PT_SPEC_TEXTURE_ILLUMINANT_SRGB ? 1u : 2u, lut = (uint32_t)in.c[0];
+            if (sub == 1u && (!(in.c[0] >= 0.0f) || lut >= luts.size())) { *err = "Illuminant texture: c[0] must hold the LUT470 id of the illuminant"; return MI355PT_E_INVALID; }
+            out->kind = SPK_TEXTURE; out->id = in.id;
+            std::memcpy(&out->c[0], &sub, 4); std::memcpy(&out->c[1], &lut, 4);
+            return MI355PT_OK;
+        }
         default: *err = "unknown spectrum kind"; return MI355PT_E_INVALID;
     }
 }
@@ -567,7 +578,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         if (m.type == MT_GLASS || m.type == MT_PLASTIC) features |= FEAT_DIEL | ((m.roughness >= 1e-3f || m.roughness_tex != 0xffffffffu) ? FEAT_ROUGH : 0u);
         if (m.type == MT_CLEARCOAT) features |= FEAT_CC;
         if (m.type == MT_METAL) features |= FEAT_METAL;
-        if (m.type == MT_EMISSIVE && m.color.kind == SPK_TEXTURE) features |= FEAT_EMTEX;
+        if (m.type == MT_EMISSIVE && (m.color.kind == SPK_TEXTURE || m.metallic_tex != 0xffffffffu)) features |= FEAT_EMTEX;   // textured radiance or intensity
         if (m.normal_tex != 0xffffffffu || m.color.kind == SPK_TEXTURE || m.cc_tint.kind == SPK_TEXTURE || m.metallic_tex != 0xffffffffu ||
             m.roughness_tex != 0xffffffffu || m.cc_thickness_tex != 0xffffffffu) features |= FEAT_TEX;
     }

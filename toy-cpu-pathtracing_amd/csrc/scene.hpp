@@ -79,7 +79,7 @@ struct SceneImpl {
     void release();
     // RgbSigmoidPolynomial::from(ColorSrgb) on the host (rgb_sigmoid_polynomial.rs:87-155)
     bool table_lookup_srgb(const float rgb_encoded[3], float c[3], bool linear = false) const;
-    int lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, bool allow_texture, std::string* err) const;
+    int lower_spectrum(const mi355pt_spectrum& in, DevSpectrum* out, int allow_texture /* 0 no, 1 Albedo type, 2 every SpectrumType */, std::string* err) const;
     int build(const mi355pt_camera* cam, const float* cmf_xyz /*3*470*/, std::string* err);
 };
 

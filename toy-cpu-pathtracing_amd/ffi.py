@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(HERE, "csrc", "libmi355
 
 NONE = 0xFFFFFFFF
 SPEC_CONSTANT, SPEC_RGB_ALBEDO_SRGB, SPEC_LUT470, SPEC_TEXTURE_ALBEDO_SRGB, SPEC_SIGMOID, SPEC_RGB_ALBEDO_SRGB_LINEAR = 0, 1, 2, 3, 4, 5
+SPEC_TEXTURE_ILLUMINANT_SRGB, SPEC_TEXTURE_UNBOUNDED_SRGB = 6, 7
 MAT_LAMBERT, MAT_EMISSIVE, MAT_GLASS, MAT_PLASTIC, MAT_CLEARCOAT, MAT_METAL, MAT_SIMPLE_PBR = 0, 1, 2, 3, 4, 5, 6
 STRATEGY = {"pt": 0, "nee": 1, "mis": 2}
 SAMPLER = {"random": 0, "sobol": 1}
@@ -47,17 +48,27 @@ class Spectrum(C.Structure):
     def texture_albedo_srgb(i):
         return Spectrum(SPEC_TEXTURE_ALBEDO_SRGB, i, (C.c_float * 3)(0, 0, 0))
 
+    @staticmethod
+    def texture_illuminant_srgb(i, illuminant_lut):
+        """SpectrumParameter::texture(.., SpectrumType::Illuminant): c[0] carries the LUT470 id of presets::cie_illum_d6500()"""
+        return Spectrum(SPEC_TEXTURE_ILLUMINANT_SRGB, i, (C.c_float * 3)(float(illuminant_lut), 0, 0))
+
+    @staticmethod
+    def texture_unbounded_srgb(i):
+        return Spectrum(SPEC_TEXTURE_UNBOUNDED_SRGB, i, (C.c_float * 3)(0, 0, 0))
+
 
 class MaterialDesc(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color", Spectrum), ("normal_tex", C.c_uint32), ("normal_flip_y", C.c_uint32),
                 ("intensity", C.c_float), ("eta", Spectrum), ("thin", C.c_uint32), ("roughness", C.c_float),
                 ("metallic", C.c_float), ("ior", C.c_float), ("clearcoat_ior", C.c_float), ("clearcoat_roughness", C.c_float),
                 ("clearcoat_thickness", C.c_float), ("clearcoat_tint", Spectrum), ("k", Spectrum),
-                ("metallic_tex", C.c_uint32), ("roughness_tex", C.c_uint32), ("clearcoat_thickness_tex", C.c_uint32)]
+                ("metallic_tex", C.c_uint32), ("roughness_tex", C.c_uint32), ("clearcoat_thickness_tex", C.c_uint32),
+                ("intensity_tex", C.c_uint32)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
-        self.metallic_tex = NONE; self.roughness_tex = NONE; self.clearcoat_thickness_tex = NONE
+        self.metallic_tex = NONE; self.roughness_tex = NONE; self.clearcoat_thickness_tex = NONE; self.intensity_tex = NONE
 
 
 LIGHT_POINT, LIGHT_SPOT, LIGHT_DIRECTIONAL = 1, 2, 3

@@ -411,13 +411,13 @@ inline ImageRgb8 load_image(const std::string& path) {      // by extension: .pn
 }
 struct RgbTexture { std::shared_ptr<ImageRgb8> img; static RgbTexture load_srgb(const std::string& p) { return {std::make_shared<ImageRgb8>(load_image(p))}; } };
 struct NormalTexture { std::shared_ptr<ImageRgb8> img; bool flip_y; static NormalTexture load(const std::string& p, bool flip_y) { return {std::make_shared<ImageRgb8>(load_image(p)), flip_y}; } };
-enum class SpectrumType { Albedo };
+enum class SpectrumType { Albedo, Illuminant, Unbounded };      // texture/config.rs; Illuminant / Unbounded: emitter radiance (rgb_texture.rs:56-64)
 
 // ------------------------------------------------------------------ parameters (scene/src/material/parameter.rs)
 struct SpectrumParameter {
-    bool is_texture = false; Spectrum spectrum; RgbTexture tex;
+    bool is_texture = false; Spectrum spectrum; RgbTexture tex; SpectrumType tex_type = SpectrumType::Albedo;
     static SpectrumParameter constant(Spectrum s) { SpectrumParameter p; p.spectrum = std::move(s); return p; }
-    static SpectrumParameter texture(RgbTexture t, SpectrumType) { SpectrumParameter p; p.is_texture = true; p.tex = std::move(t); return p; }
+    static SpectrumParameter texture(RgbTexture t, SpectrumType ty) { SpectrumParameter p; p.is_texture = true; p.tex = std::move(t); p.tex_type = ty; return p; }
 };
 struct FloatTexture {                                          // texture/float_texture.rs:24-31 (gamma_corrected = false only)
     std::shared_ptr<ImageRgb8> img;
@@ -443,9 +443,10 @@ struct Material {
     float metallic = 0, ior = 1.5f, clearcoat_ior = 1.5f, clearcoat_roughness = 0, clearcoat_thickness = 0; SpectrumParameter clearcoat_tint;
     Spectrum k;   // metal: extinction coefficient
     std::shared_ptr<ImageRgb8> metallic_tex, roughness_tex, clearcoat_thickness_tex;   // FloatParameter::texture (grey image replicated to RGB)
+    std::shared_ptr<ImageRgb8> intensity_tex;                                          // emissive: FloatParameter::texture intensity
 };
 struct LambertMaterial { static Material create(SpectrumParameter albedo, NormalParameter n) { Material m; m.type = MI355PT_MAT_LAMBERT; m.color = std::move(albedo); m.normal = std::move(n); return m; } };
-struct EmissiveMaterial { static Material create(SpectrumParameter radiance, FloatParameter intensity) { Material m; m.type = MI355PT_MAT_EMISSIVE; m.color = std::move(radiance); m.intensity = intensity.v; return m; } };
+struct EmissiveMaterial { static Material create(SpectrumParameter radiance, FloatParameter intensity) { Material m; m.type = MI355PT_MAT_EMISSIVE; m.color = std::move(radiance); m.intensity = intensity.v; m.intensity_tex = intensity.tex; return m; } };
 enum class GlassType { Bk7, Sf11 };
 struct GlassMaterial {
     static Material create(GlassType t, NormalParameter n, bool thin, FloatParameter rough) {
@@ -647,6 +648,7 @@ public:
         if (m.metallic_tex) md.metallic_tex = add_tex(*m.metallic_tex);
         if (m.roughness_tex) md.roughness_tex = add_tex(*m.roughness_tex);
         md.clearcoat_thickness_tex = m.clearcoat_thickness_tex ? add_tex(*m.clearcoat_thickness_tex) : MI355PT_NONE;
+        md.intensity_tex = (m.type == MI355PT_MAT_EMISSIVE && m.intensity_tex) ? add_tex(*m.intensity_tex) : MI355PT_NONE;
         if (m.normal.has) { md.normal_tex = add_tex(*m.normal.tex.img); md.normal_flip_y = m.normal.tex.flip_y ? 1 : 0; }
         md.intensity = m.intensity; md.thin = m.thin ? 1 : 0; md.roughness = m.roughness;
         if (m.type == MI355PT_MAT_GLASS || m.type == MI355PT_MAT_PLASTIC || m.type == MI355PT_MAT_METAL) md.eta = lower_spectrum(m.eta);
@@ -705,7 +707,10 @@ private:
     }
     mi355pt_spectrum lower(const SpectrumParameter& p) {
         if (!p.is_texture) return lower_spectrum(p.spectrum);
-        mi355pt_spectrum s{}; s.kind = MI355PT_SPEC_TEXTURE_ALBEDO_SRGB; s.id = add_tex(*p.tex.img); return s;
+        mi355pt_spectrum s{}; s.id = add_tex(*p.tex.img);
+        s.kind = p.tex_type == SpectrumType::Albedo ? MI355PT_SPEC_TEXTURE_ALBEDO_SRGB : (p.tex_type == SpectrumType::Illuminant ? MI355PT_SPEC_TEXTURE_ILLUMINANT_SRGB : MI355PT_SPEC_TEXTURE_UNBOUNDED_SRGB);
+        if (p.tex_type == SpectrumType::Illuminant) s.c[0] = (float)lower_spectrum(presets::cie_illum_d6500()).id;     // RgbIlluminantSpectrum's illuminant (rgb_illuminant_spectrum.rs:27)
+        return s;
     }
     mi355pt_scene* s_ = nullptr;
     bool multi_ = false;

@@ -355,6 +355,25 @@ def load_scene(scene, scene_id, width, height, tex_size=1024, build=True):
         em = MaterialDesc(); em.type = MAT_EMISSIVE; em.color = Spectrum.texture_albedo_srgb(scene.add_tex_rgb8(albedo)); em.intensity = 12.0; em.normal_tex = NONE
         scene.add_instance(scene.add_mesh(panel), scene.add_material(em))
         cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
+    elif scene_id in (31, 32):   # not reference scenes: the textured emitter of scene 30 with an ILLUMINANT-type (31) / UNBOUNDED-type (32) radiance
+        # texture (rgb_texture.rs:56-64: RgbIlluminantSpectrum / RgbUnboundedSpectrum of every texel) AND a FloatParameter::texture intensity
+        # (emissive_material.rs:55-56: a horizontal ramp, read at the hit / sampled uv; the light-pick weight takes both at uv (0.5, 0.5), :63-79)
+        g = scene.add_mesh(_asset("bunny"))
+        scene.add_instance(g, scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
+        _room(scene, p, with_light=False)
+        albedo, _ = _asset(f"tex{min(tex_size, 256)}")
+        panel = assets.load_obj_semantics(dict(pos=np.array([[-0.9, 3.95, -0.9], [0.9, 3.95, -0.9], [0.9, 3.95, 0.9], [-0.9, 3.95, 0.9]], np.float32),
+                                               nrm=np.array([[0, -1, 0]] * 4, np.float32), uv=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32),
+                                               idx=np.array([[0, 1, 2], [0, 2, 3]], np.uint32)))
+        ramp = np.repeat(np.tile(np.linspace(40, 255, 64).astype(np.uint8)[None, :], (16, 1))[..., None], 3, axis=2).copy()   # grey image, red channel read
+        t_col, t_int = scene.add_tex_rgb8(albedo), scene.add_tex_rgb8(ramp)
+        em = MaterialDesc(); em.type = MAT_EMISSIVE; em.normal_tex = NONE; em.intensity = 1.0; em.intensity_tex = t_int
+        if scene_id == 31:
+            em.color = Spectrum.texture_illuminant_srgb(t_col, scene.add_lut470(p["cie_illum_d6500"]))
+        else:
+            em.color = Spectrum.texture_unbounded_srgb(t_col)
+        scene.add_instance(scene.add_mesh(panel), scene.add_material(em))
+        cam = make_camera((0.0, 3.15221, 6.0), (0.0, -0.9, -3.2), (0.0, 1.0, 0.0), width, height)
     else:
         raise ValueError(f"scene {scene_id} is outside the hot-path scope (SURVEY.md §8)")
     if build:
