@@ -146,8 +146,20 @@ constexpr size_t defer_bytes_per_wave() { return PT_DEFER ? (size_t)DEFER_RING *
 #define PT_WIDE_BVH 1
 #endif
 template <uint32_t FEAT> constexpr bool wide_bvh() { return PT_WIDE_BVH != 0; }
+// Waves per SIMD of the clearcoat kernels.  Round 2: 3 (168 VGPRs) with the spawning sample's record parked in LDS.  Since the material sort
+// moved most clearcoat shading into dedicated passes (PT_DEFER), the common iteration is the room's: the kernels whose clearcoat code is not
+// ALSO carrying the texture code gain from a fourth wave (128 VGPRs, no parking: the LDS is needed for 16 waves) — scene 17 NEE (C5) +1.8 %,
+// scene 19 (all-features kernel) +3.6 %, scenes 16 / 17 MIS +0 ... 0.5 %; the clearcoat + texture set loses 5.8 % (scene 15: 276 B of scratch) and stays at 3.
+#ifndef PT_CC_WAVES_SEL
+#define PT_CC_WAVES_SEL 1
+#endif
+template <uint32_t FEAT> constexpr int kernel_min_waves() {
+    if ((FEAT & FEAT_CC) == 0u) return PT_MIN_WAVES;
+    if (PT_CC_WAVES_SEL != 0 && FEAT != (FEAT_CC | FEAT_TEX)) return 4;
+    return PT_MIN_WAVES_CC;
+}
 template <bool STATS, uint32_t FEAT, uint32_t MODE = MODE_GENERIC>
-__global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WAVES)) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm_in, const uint64_t* __restrict__ dim_hash_tab,
+__global__ __launch_bounds__(64, kernel_min_waves<FEAT>()) void pt_kernel(DevScene sc, DevCamera cam, DevParams prm_in, const uint64_t* __restrict__ dim_hash_tab,
                                                 float* __restrict__ accum, float* __restrict__ partial, unsigned* __restrict__ work_counter,
                                                 DevStats* __restrict__ stats, PathOut pout, float4* __restrict__ defer_buf) {
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(64, ((FEAT & FEAT_CC) ? PT_MIN_WAVES_CC : PT_MIN_WA
     // The clearcoat kernels run 12 waves per CU, so each has 3.4 KB of LDS the 16-wave kernels do not: the record of the BSDF sample that
     // spawned the ray in flight (f, pdf, the vertex left: 8 dwords per lane, read only at the start of the next vertex's shading) waits there
     // during the traversals instead of in registers the allocator would spill to scratch
-    constexpr bool PARK = PT_PARK_LDS != 0 && (FEAT & FEAT_CC) != 0u;
+    constexpr bool PARK = PT_PARK_LDS != 0 && (FEAT & FEAT_CC) != 0u && kernel_min_waves<FEAT>() <= 3;
     __shared__ float s_park[PARK ? 8 * 64 : 1];
     __shared__ uint8_t s_perm[96];
 #if PT_ANY_DEFERRED
