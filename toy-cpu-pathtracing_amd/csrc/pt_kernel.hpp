@@ -134,7 +134,35 @@ template <uint32_t FEAT, uint32_t MODE> constexpr uint32_t defer_classes() {    
     if (PT_DEFER_TEX != 0 && (FEAT & FEAT_TEX) != 0u) return 0xff00u;
     return 0u;
 }
-constexpr size_t defer_bytes_per_wave() { return PT_DEFER ? (size_t)DEFER_RING * DEFER_F4 * 16u : 0u; }
+// TAIL QUEUE (PT_TAILQ): the same idea for EVERY path.  A third of the lanes that enter the shading stage end their path in its front
+// (emission, roulette) and used to idle through BSDF sampling and the light connection — 28 % of a wave's time at 65 % of its lanes.  Now the
+// shading stage is two: (1) the FRONT of the vertex for every lane that traced (emission with its weight, throughput, roulette, depth:
+// shade_vertex_head<PHASE 1>); the paths that go on are written to the wave's queue (path + hit, the 128-byte record of PT_DEFER) and ALL
+// lanes are free; (2) when 64 paths wait, one pass takes them into the free lanes and runs the back of the vertex (the surface again from
+// the hit, frames, the BSDF's draws: <PHASE 2>) and the tail — BSDF sample, light connection — for a FULL wave.  Lanes left free start new
+// camera paths as before.  In the clearcoat kernels the paths whose hit is on the clearcoat material have a queue of their own, so a pass
+// shades one class (this subsumes PT_DEFER there); when a work item has nothing new left, whatever waits shares the passes.  A sample's
+// arithmetic and its sampler dimensions are what they were — the record carries the path between the two halves of ITS vertex —, the
+// queues belong to the wave that owns the pixels, the schedule is the wave's own: frames bit-identical from run to run, 166 GPU tests
+// unchanged.  Same-box A/B (round 3): **C2 2 088 -> 2 312 Msamples/s (+10.7 %), C3 +11.9 %, C4 +13.2 %, C5 1 574 -> 1 893 (+20 %)**, scene 19
+// +37 %, scene 15 +22 %, scenes 0 / 5 +10 / +12 %.  Measured on the way: a threshold of 48 instead of 64 waiting paths gives +7 % instead of
+// +10.7 % (passes not full); a second queue for every class but plain Lambert in the kernels WITHOUT clearcoat loses everything again
+// (a class that is a tenth of the hits leaves up to 63 paths to be bounced out in sparse passes at the end of every work item); writing
+// the pass with the back of the head and the tail in two divergent regions instead of one costs those kernels 12 % (ShadeCtx across a
+// re-convergence point at 128 VGPRs, as round 1 found for the fused shader).
+#ifndef PT_TAILQ
+#define PT_TAILQ 1
+#endif
+#ifndef PT_TAILQ_MIN
+#define PT_TAILQ_MIN 64
+#endif
+#ifndef PT_TAILQ_CC
+#define PT_TAILQ_CC 1        // the clearcoat kernels too (two queues: one per sort class)
+#endif
+template <uint32_t FEAT, uint32_t MODE> constexpr bool tail_queue() { return PT_TAILQ != 0 && merged_traversal<FEAT, MODE>() && ((FEAT & FEAT_CC) == 0u || PT_TAILQ_CC != 0); }
+constexpr uint32_t QUEUE_RING = (PT_TAILQ != 0) ? 256u : DEFER_RING;     // entries per wave and queue
+constexpr uint32_t QUEUE_MAX = (PT_TAILQ != 0) ? 2u : 1u;               // queues per wave (the tail queue keeps one per sort class)
+constexpr size_t defer_bytes_per_wave() { return (PT_DEFER || PT_TAILQ) ? (size_t)QUEUE_MAX * QUEUE_RING * DEFER_F4 * 16u : 0u; }
 // MODE compiles the renderer strategy and the sampler in (MODE_GENERIC reads them from DevParams): the branches on
 // prm.strategy / the sampler mode fold away, worth +2.5 % on C2 (MIS + Sobol), +1.3 % on C5 (NEE + Sobol).
 // Which tree the cooperative traversals walk (both are on the device; the plain traversals of the probes and of the canonical-count
@@ -279,9 +307,16 @@ __global__ __launch_bounds__(64, kernel_min_waves<FEAT>()) void pt_kernel(DevSce
         // `susp` (carry-over): this lane's closest-hit ray is still in flight, the lane sits out the shading stage
         bool dying = false, susp = false;
         CarryState carry{0ull};
-        constexpr uint32_t DEFER = defer_classes<FEAT, MODE>();
-        float4* const q_base = DEFER ? defer_buf + (size_t)blockIdx.x * (DEFER_RING * DEFER_F4) : nullptr;     // this wave's queue
+        constexpr bool TAILQ = !STATS && tail_queue<FEAT, MODE>();       // (the instrumented kernels keep the plain shading stage)
+        constexpr uint32_t DEFER = TAILQ ? 0u : defer_classes<FEAT, MODE>();
+        float4* const q_base = (DEFER != 0u || TAILQ) ? defer_buf + (size_t)blockIdx.x * (QUEUE_MAX * QUEUE_RING * DEFER_F4) : nullptr;     // this wave's queue(s)
         uint32_t q_head = 0u, q_tail = 0u;                         // wave-uniform; the queue is empty between work items
+        // tail queue: a second queue for the paths whose hit is on a sort class of its own (defer_classes), so that a pass shades one class
+        // (the clearcoat material in the kernels that have it: its branch is the long one.  A second queue for every class but plain Lambert
+        // was measured on the kernels without clearcoat and LOSES — scene 3 2 312 -> 2 063, scene 8 2 097 -> 1 932: a class that is a tenth of
+        // the hits fills its queue every ~16 iterations and leaves up to 63 paths to be bounced out in sparse passes when a work item ends)
+        constexpr uint32_t TQ_CLASSES = (TAILQ && (FEAT & FEAT_CC) != 0u) ? ((1u << MT_CLEARCOAT) | (1u << (MT_CLEARCOAT | 8u))) : 0u;
+        uint32_t q2_head = 0u, q2_tail = 0u;
         while (true) {
             unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0;
             uint32_t bsdf_classes = 0u;
@@ -312,9 +347,9 @@ __global__ __launch_bounds__(64, kernel_min_waves<FEAT>()) void pt_kernel(DevSce
                 pool_next = min(pool_next + (uint32_t)__popcll(m_needy), pool_size);
             }
             if (!__any(active)) {
-                if (pool_next >= pool_size && q_tail == q_head) break;
+                if (pool_next >= pool_size && q_tail == q_head && q2_tail == q2_head) break;
                 // (PT_DEFER 2 takes queued paths AFTER the shading stage: with nothing left to start, an iteration without rays still has to get there)
-                if (!(DEFER != 0u && PT_DEFER == 2 && pool_next >= pool_size)) continue;
+                if (!(((DEFER != 0u && PT_DEFER == 2) || TAILQ) && pool_next >= pool_size)) continue;
             }
             if (STATS) { ts1 = __builtin_amdgcn_s_memtime(); if (lane == 0) st.w[4]++; if (active) st.w[5]++; }
             Hit hit{};
@@ -347,6 +382,115 @@ __global__ __launch_bounds__(64, kernel_min_waves<FEAT>()) void pt_kernel(DevSce
                 bsdf_classes = classes - (__ballot(mclass == MT_EMISSIVE) != 0ull ? 1u : 0u);
                 ts2 = __builtin_amdgcn_s_memtime();
             }
+            auto q_store = [&](uint32_t e, const Path& Q, const Hit& h, uint32_t pix) {
+                float4* r = q_base + (size_t)e * DEFER_F4;
+                const uint32_t fl = (Q.wl.term ? 1u : 0u) | (Q.from_camera ? 2u : 0u) | (Q.prev_spec ? 4u : 0u) | ((Q.depth & 255u) << 8) | (pix << 16);
+                r[0] = make_float4(__uint_as_float(Q.smp.morton), __uint_as_float(Q.smp.dimension), __uint_as_float(Q.smp.rkey_lo), __uint_as_float(Q.smp.rkey_hi));
+                r[1] = make_float4(Q.wl.lam0, __uint_as_float(fl), Q.T[0], Q.T[1]);
+                r[2] = make_float4(Q.T[2], Q.T[3], Q.L[0], Q.L[1]);
+                r[3] = make_float4(Q.L[2], Q.L[3], Q.rd.x, Q.rd.y);
+                r[4] = make_float4(Q.rd.z, Q.pf[0], Q.pf[1], Q.pf[2]);
+                r[5] = make_float4(Q.pf[3], Q.p_pdf, Q.prev_pos.x, Q.prev_pos.y);
+                r[6] = make_float4(Q.prev_pos.z, h.t, h.b0, h.b1);
+                r[7] = make_float4(h.b2, __uint_as_float(h.tri), __uint_as_float(h.mclass), 0.0f);
+            };
+            auto q_load = [&](uint32_t e, Path& Q, Hit& h, uint32_t& pix) {
+                const float4* r = q_base + (size_t)e * DEFER_F4;
+                const float4 a = r[0], b = r[1], c = r[2], d = r[3], e4 = r[4], f = r[5], g = r[6], hh = r[7];
+                const uint32_t fl = __float_as_uint(b.y);
+                Q.smp.morton = __float_as_uint(a.x); Q.smp.dimension = __float_as_uint(a.y); Q.smp.rkey_lo = __float_as_uint(a.z); Q.smp.rkey_hi = __float_as_uint(a.w);
+                Q.wl.lam0 = b.x; Q.wl.term = (fl & 1u) != 0u; Q.from_camera = (fl & 2u) != 0u; Q.prev_spec = (fl & 4u) != 0u; Q.depth = (fl >> 8) & 255u; pix = fl >> 16;
+                Q.T[0] = b.z; Q.T[1] = b.w; Q.T[2] = c.x; Q.T[3] = c.y; Q.L[0] = c.z; Q.L[1] = c.w; Q.L[2] = d.x; Q.L[3] = d.y;
+                Q.rd = mk3(d.z, d.w, e4.x); Q.ro = mk3(0.0f, 0.0f, 0.0f);
+                Q.pf[0] = e4.y; Q.pf[1] = e4.z; Q.pf[2] = e4.w; Q.pf[3] = f.x; Q.p_pdf = f.y; Q.prev_pos = mk3(f.z, f.w, g.x);
+                h.t = g.y; h.b0 = g.z; h.b1 = g.w; h.b2 = hh.x; h.tri = __float_as_uint(hh.y); h.mclass = __float_as_uint(hh.z);
+            };
+            auto finish_path = [&]() {            // Sensor::add_sample of a finished path into the work item's LDS film tile (+ the per-sample log)
+                if (pout.L != nullptr) {
+                    const uint32_t px = job0.px + (my_pix & blk_mask), py = job0.py + (my_pix >> blk_log2);
+                    const uint32_t tile_k = (work / prm.chunks) >> (6u - 2u * blk_log2);
+                    const uint32_t smp_i = P.smp.morton & ((1u << prm.log2_spp) - 1u);
+                    sample_log(P, pout, ((size_t)tile_k * 64u + ((py & 7u) * 8u + (px & 7u))) * pout.n_s + (smp_i - pout.s_base));
+                }
+                float r, g, b;
+                film_rgb(P, sc, prm, r, g, b);
+                atomicAdd(&s_film[3 * my_pix], r); atomicAdd(&s_film[3 * my_pix + 1], g); atomicAdd(&s_film[3 * my_pix + 2], b);
+            };
+            if constexpr (TAILQ) {
+                // front of the vertex for every lane that traced: does the path go on?
+                bool end_path = dying;                         // (a dying path's last connection has just been resolved)
+                const bool front = active && !dying && !susp;
+                unpark(P);
+                {
+                    ShadeCtx C0;
+                    C0.cont = false;
+                    if (front) end_path = shade_vertex_head<STATS, FEAT, 1>(P, sc, prm, sctx, got, hit, sh, st, tsa, C0);
+                }
+                dying = false;
+                // the paths that go on wait in the queue of their sort class; their lanes are free
+                const bool go_on = front && !end_path;
+                const bool cls2 = TQ_CLASSES != 0u && ((TQ_CLASSES >> (hit.mclass & 31u)) & 1u) != 0u;
+                const unsigned long long m_on1 = __ballot(go_on && !cls2), m_on2 = TQ_CLASSES != 0u ? __ballot(go_on && cls2) : 0ull;
+                if ((m_on1 | m_on2) != 0ull) {
+                    if (go_on) {
+                        const uint32_t e = cls2 ? QUEUE_RING + ((q2_tail + rank_below(m_on2)) & (QUEUE_RING - 1u)) : ((q_tail + rank_below(m_on1)) & (QUEUE_RING - 1u));
+                        q_store(e, P, hit, my_pix);
+                        active = false;
+                    }
+                    q_tail += (uint32_t)__popcll(m_on1); q2_tail += (uint32_t)__popcll(m_on2);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                }
+                if (active && end_path) { finish_path(); active = false; }
+                park(P, false);                                 // (nothing of these lanes' records is needed any more: the queue has them)
+                if (STATS) ts3 = ts4 = __builtin_amdgcn_s_memtime();
+                // the back of the vertex and its tail for a full wave of queued paths — of ONE class while new paths still arrive (the class
+                // with its own queue first); when the work item has nothing new left, whatever waits in either queue shares the passes
+                const bool draining = pool_next >= pool_size;
+                const uint32_t c2 = q2_tail - q2_head, c1 = q_tail - q_head;
+                const bool full2 = TQ_CLASSES != 0u && c2 >= (uint32_t)PT_TAILQ_MIN, full1 = c1 >= (uint32_t)PT_TAILQ_MIN;
+                if (full2 || full1 || (draining && (c1 | c2) != 0u)) {
+                    const unsigned long long m_free = __ballot(!active);
+                    const uint32_t n_free = (uint32_t)__popcll(m_free), r = rank_below(m_free);
+                    // lanes 0 .. n2-1 of the free lanes take from queue 2, the next n1 from queue 1
+                    const uint32_t n2 = (full2 || (draining && !full1)) ? min(n_free, c2) : 0u;
+                    const uint32_t n1 = (!full2 || draining) ? min(n_free - n2, c1) : 0u;
+                    const bool take2 = !active && r < n2, take1 = !active && !take2 && r - n2 < n1;
+                    const bool take = take1 || take2;
+                    const uint32_t e = take2 ? QUEUE_RING + ((q2_head + r) & (QUEUE_RING - 1u)) : ((q_head + (r - n2)) & (QUEUE_RING - 1u));
+                    q2_head += n2; q_head += n1;
+                    bool ep = false;
+                    if constexpr ((FEAT & FEAT_CC) != 0u) {
+                        ShadeCtx C;
+                        C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
+                        if (take) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            q_load(e, P, hit, my_pix);
+                            active = true;
+                            shade_vertex_head<STATS, FEAT, 2>(P, sc, prm, sctx, true, hit, sh, st, tsa, C);
+                        }
+                        // the coat's 64-sample directional albedo, estimated by the whole wave for the lanes that need it
+                        const bool want_mc = take && C.cont && C.need_cc;
+                        const float fc_mc = coat_directional_albedo_coop(want_mc, C.cc_alpha_c, C.cc_r0c, C.wo_nm, C.mc_key, lane);
+                        if (want_mc) C.cc_fc = fc_mc;
+                        if (take && C.cont) ep = shade_vertex_tail<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
+                    } else if (take) {
+                        // (ONE divergent region for the back of the head and the tail: ShadeCtx must not cross a re-convergence point in the
+                        // kernels that run 4 waves per SIMD — the split form of this block cost them 12 %)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        q_load(e, P, hit, my_pix);
+                        active = true;
+                        ShadeCtx C;
+                        C.cont = false; C.need_cc = false; C.cc_fc = 0.0f;
+                        shade_vertex_head<STATS, FEAT, 2>(P, sc, prm, sctx, true, hit, sh, st, tsa, C);
+                        if (C.cont) ep = shade_vertex_tail<STATS, FEAT>(P, sc, prm, sctx, sh, st, tsb, C);
+                    }
+                    park(P, take);
+                    if (sh.on && sh.c[0] == 0.0f && sh.c[1] == 0.0f && sh.c[2] == 0.0f && sh.c[3] == 0.0f) sh.on = false;
+                    if (!active) sh.on = false;
+                    if (take) { dying = sh.on && ep; if (dying) ep = false; }
+                    if (take && ep) { finish_path(); active = false; }
+                }
+            } else
             // The shading stage.  PT_DEFER 2 runs it a second time in the iterations that shade the deferral queue: the lanes the first pass
             // freed (ended paths, deferred hits) take queued paths and shade them at once, so a queued path rejoins the NEXT traversal
             // with its next ray like everybody else (PT_DEFER 1 pops at the top of the iteration and lets those lanes sit out a traversal).

@@ -283,7 +283,11 @@ struct ShadeCtx {
     bool need_cc; float cc_alpha_c, cc_r0c, cc_thick, cc_metallic, cc_rough_b, cc_fc; uint64_t mc_key;
 };
 
-template <bool STATS, uint32_t FEAT>
+// PHASE (the tail queue of pt_kernel.hpp, PT_TAILQ): 0 = the whole first half; 1 = only its front — emission with the strategy's weight,
+// throughput, Russian roulette, the depth test: what decides whether the path goes on —; 2 = only its back for a path that went on — the
+// surface again from the hit, shading frames, the BSDF's random numbers — whose result feeds shade_vertex_tail.  1 then 2 on the same
+// (P, hit) compute exactly what 0 computes: the sampler's dimensions are consumed in the same order.
+template <bool STATS, uint32_t FEAT, int PHASE = 0>
 PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm, const SamplerCtx& sctx, bool got, const Hit& hit, ShadowReq& sh,
                            StatCounters& st, unsigned long long& tsa, ShadeCtx& C) {
     Sampler& smp = P.smp; Wl& wl = P.wl; float* T = P.T; float* L = P.L; f3& ro = P.ro; f3& rd = P.rd;
@@ -293,7 +297,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
     bool& do_shadow = sh.on; f3& sh_o = sh.o; f3& sh_d = sh.d; float& sh_t = sh.t; float* sh_c = sh.c;
     do_shadow = false;
 
-    if (!got) {
+    if (PHASE != 2 && !got) {
         end_path = true;
         if ((FEAT & FEAT_ENV) && sc.n_envs != 0u) {
             float rad[4];
@@ -347,8 +351,9 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
         Surface sf = load_surface(sc, hit);
         const DevMaterial* mat = sc.materials + sf.material;
         const uint32_t mtype = mat->type;
-        const bool emissive = mtype == MT_EMISSIVE;
+        const bool emissive = PHASE != 2 && mtype == MT_EMISSIVE;            // (PHASE 2: the path went on, so the surface is not an emitter)
         float Le[4] = {0, 0, 0, 0};
+        if constexpr (PHASE != 2) {
         if (emissive) {                                                      // evaluate_emissive_surface :54-73
             DevSpectrum rs = load_spectrum(&mat->color);
             eval_spectrum<STATS, (FEAT & FEAT_EMTEX) != 0, (FEAT & FEAT_EMTEX) != 0>(sc, rs, wl, sf.uv, Le, st);
@@ -442,7 +447,8 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             depth += 1;                                                       // for _ in 1..=max_depth (:197)
             if (depth > prm.max_depth || emissive) end_path = true;           // as_bsdf_material() == None (:199-202)
         }
-        if (!end_path) {
+        }   // PHASE != 2
+        if (PHASE != 1 && !end_path) {
             if (STATS) { st.bounces++; tsa = __builtin_amdgcn_s_memtime(); }
             Frame fr, fw_num;
             if constexpr (numeric_frames<FEAT>()) shading_frames_numeric(sf.ns, sf.tangent, fr, fw_num);
