@@ -205,6 +205,7 @@ int check_args(const mi355pt_scene* s, const mi355pt_camera* cam, const mi355pt_
     if (!s->impl.built) return fail(MI355PT_E_NOT_BUILT, "scene not built");
     if (cam->width == 0 || cam->height == 0 || p->spp == 0) return fail(MI355PT_E_INVALID, "empty image or spp == 0");
     if (p->strategy > 2 || p->sampler > 1) return fail(MI355PT_E_INVALID, "bad strategy/sampler");
+    if (p->max_depth > 1000u) return fail(MI355PT_E_INVALID, "max_depth > 1000 (the path records of the kernel's queues hold the depth in 10 bits and the sampler dimension in 15)");
     if (!(p->rr_gate_slack >= 0.0f && p->rr_gate_slack < 1.0f)) return fail(MI355PT_E_INVALID, "rr_gate_slack must be in [0, 1)");
     if (p->rr_gate_slack != 0.0f && !g_debug_unlocked)
         return fail(MI355PT_E_INVALID, "mi355pt_params.rr_gate_slack must be 0 (a diagnostic: mi355pt_debug_unlock(1) in mi355pt_debug.h enables it)");

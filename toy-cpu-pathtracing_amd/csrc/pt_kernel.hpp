@@ -162,6 +162,7 @@ template <uint32_t FEAT, uint32_t MODE> constexpr uint32_t defer_classes() {    
 template <uint32_t FEAT, uint32_t MODE> constexpr bool tail_queue() { return PT_TAILQ != 0 && merged_traversal<FEAT, MODE>() && ((FEAT & FEAT_CC) == 0u || PT_TAILQ_CC != 0); }
 constexpr uint32_t QUEUE_RING = (PT_TAILQ != 0) ? 256u : DEFER_RING;     // entries per wave and queue
 constexpr uint32_t QUEUE_MAX = (PT_TAILQ != 0) ? 2u : 1u;               // queues per wave (the tail queue keeps one per sort class)
+constexpr uint32_t TQ_F4 = 5u;                                           // float4 per record of the tail queue (80 B; PT_DEFER's record: 8)
 constexpr size_t defer_bytes_per_wave() { return (PT_DEFER || PT_TAILQ) ? (size_t)QUEUE_MAX * QUEUE_RING * DEFER_F4 * 16u : 0u; }
 // MODE compiles the renderer strategy and the sampler in (MODE_GENERIC reads them from DevParams): the branches on
 // prm.strategy / the sampler mode fold away, worth +2.5 % on C2 (MIS + Sobol), +1.3 % on C5 (NEE + Sobol).
@@ -405,6 +406,32 @@ __global__ __launch_bounds__(64, kernel_min_waves<FEAT>()) void pt_kernel(DevSce
                 Q.pf[0] = e4.y; Q.pf[1] = e4.z; Q.pf[2] = e4.w; Q.pf[3] = f.x; Q.p_pdf = f.y; Q.prev_pos = mk3(f.z, f.w, g.x);
                 h.t = g.y; h.b0 = g.z; h.b1 = g.w; h.b2 = hh.x; h.tri = __float_as_uint(hh.y); h.mclass = __float_as_uint(hh.z);
             };
+            // the tail queue's record: what the back of the vertex still needs once the front has run — the spawning sample's f, pdf and the
+            // vertex left are consumed by the front, from_camera / prev_spec are rewritten by the tail, the hit's t is never read: 20 dwords in
+            // 5 float4 = 80 B.  The record's size is the queue's price: 128 -> 96 B was worth +6.5 % on C2 (the queues stream through L2 / HBM)
+            auto tq_store = [&](uint32_t e, const Path& Q, const Hit& h, uint32_t pix) {
+                float4* r = q_base + (size_t)e * TQ_F4;
+                const uint32_t fl = (Q.wl.term ? 1u : 0u) | ((Q.depth & 1023u) << 1) | ((pix & 63u) << 11) | (Q.smp.dimension << 17);   // (max_depth <= 1000: api.cpp check_args)
+                r[0] = make_float4(__uint_as_float(Q.smp.morton), __uint_as_float(fl), Q.wl.lam0, __uint_as_float(h.tri));
+                r[1] = make_float4(Q.T[0], Q.T[1], Q.T[2], Q.T[3]);
+                r[2] = make_float4(Q.L[0], Q.L[1], Q.L[2], Q.L[3]);
+                r[3] = make_float4(Q.rd.x, Q.rd.y, Q.rd.z, h.b0);
+                r[4] = make_float4(h.b1, h.b2, __uint_as_float(Q.smp.rkey_lo), __uint_as_float(Q.smp.rkey_hi));
+            };
+            auto tq_load = [&](uint32_t e, Path& Q, Hit& h, uint32_t& pix) {
+                const float4* r = q_base + (size_t)e * TQ_F4;
+                const float4 a = r[0], b = r[1], c = r[2], d = r[3], e4 = r[4];
+                const uint32_t fl = __float_as_uint(a.y);
+                Q.smp.morton = __float_as_uint(a.x); Q.smp.dimension = fl >> 17; Q.smp.rkey_lo = __float_as_uint(e4.z); Q.smp.rkey_hi = __float_as_uint(e4.w);
+                Q.wl.lam0 = a.z; Q.wl.term = (fl & 1u) != 0u; Q.depth = (fl >> 1) & 1023u; pix = (fl >> 11) & 63u;
+                Q.from_camera = false; Q.prev_spec = false;
+                Q.T[0] = b.x; Q.T[1] = b.y; Q.T[2] = b.z; Q.T[3] = b.w; Q.L[0] = c.x; Q.L[1] = c.y; Q.L[2] = c.z; Q.L[3] = c.w;
+                Q.rd = mk3(d.x, d.y, d.z); Q.ro = mk3(0.0f, 0.0f, 0.0f);
+                h.b0 = d.w; h.b1 = e4.x; h.b2 = e4.y; h.tri = __float_as_uint(a.w); h.mclass = 0u; h.t = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Q.pf[i] = 0.0f;
+                Q.p_pdf = 0.0f; Q.prev_pos = mk3(0.0f, 0.0f, 0.0f);
+            };
             auto finish_path = [&]() {            // Sensor::add_sample of a finished path into the work item's LDS film tile (+ the per-sample log)
                 if (pout.L != nullptr) {
                     const uint32_t px = job0.px + (my_pix & blk_mask), py = job0.py + (my_pix >> blk_log2);
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(64, kernel_min_waves<FEAT>()) void pt_kernel(DevSce
                 if ((m_on1 | m_on2) != 0ull) {
                     if (go_on) {
                         const uint32_t e = cls2 ? QUEUE_RING + ((q2_tail + rank_below(m_on2)) & (QUEUE_RING - 1u)) : ((q_tail + rank_below(m_on1)) & (QUEUE_RING - 1u));
-                        q_store(e, P, hit, my_pix);
+                        tq_store(e, P, hit, my_pix);
                         active = false;
                     }
                     q_tail += (uint32_t)__popcll(m_on1); q2_tail += (uint32_t)__popcll(m_on2);
@@ -464,7 +491,7 @@ __global__ __launch_bounds__(64, kernel_min_waves<FEAT>()) void pt_kernel(DevSce
                         C.cont = false; C.need_cc = false; C.cc_fc = 0.0f; C.cc_alpha_c = 0.0f; C.cc_r0c = 0.0f; C.wo_nm = mk3(0, 0, 1); C.mc_key = 0ull;
                         if (take) {
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                            q_load(e, P, hit, my_pix);
+                            tq_load(e, P, hit, my_pix);
                             active = true;
                             shade_vertex_head<STATS, FEAT, 2>(P, sc, prm, sctx, true, hit, sh, st, tsa, C);
                         }
@@ -477,7 +504,7 @@ __global__ __launch_bounds__(64, kernel_min_waves<FEAT>()) void pt_kernel(DevSce
                         // (ONE divergent region for the back of the head and the tail: ShadeCtx must not cross a re-convergence point in the
                         // kernels that run 4 waves per SIMD — the split form of this block cost them 12 %)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        q_load(e, P, hit, my_pix);
+                        tq_load(e, P, hit, my_pix);
                         active = true;
                         ShadeCtx C;
                         C.cont = false; C.need_cc = false; C.cc_fc = 0.0f;

@@ -348,9 +348,13 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             }                                                                // nee_renderer.rs:139-153: nothing
         }
     } else {
-        Surface sf = load_surface(sc, hit);
-        const DevMaterial* mat = sc.materials + sf.material;
-        const uint32_t mtype = mat->type;
+        // PHASE 1 (the front of the tail queue's vertex) knows the material TYPE from the hit (DevTri::pad[0], Hit::mclass) and needs the surface
+        // for emitters only: every other lane skips the ten loads and the normalisations here — the back of the vertex computes the surface once
+        Surface sf; const DevMaterial* mat = nullptr; uint32_t mtype;
+        if (PHASE == 1) {
+            mtype = hit.mclass & 7u;
+            if (mtype == MT_EMISSIVE) { sf = load_surface(sc, hit); mat = sc.materials + sf.material; }
+        } else { sf = load_surface(sc, hit); mat = sc.materials + sf.material; mtype = mat->type; }
         const bool emissive = PHASE != 2 && mtype == MT_EMISSIVE;            // (PHASE 2: the path went on, so the surface is not an emitter)
         float Le[4] = {0, 0, 0, 0};
         if constexpr (PHASE != 2) {
