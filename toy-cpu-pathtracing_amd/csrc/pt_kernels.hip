@@ -11,9 +11,12 @@
 //  * waves are persistent: they pull (tile, sample-chunk) work items from a global counter;
 //  * path state never round-trips through HBM: every lane carries its path in registers and
 //    regenerates the next sample of its pixel when the path ends (in-register compaction);
-//  * inside a wave the path loop is a lock-step state machine: every iteration all 64 lanes trace one closest-hit
-//    ray together, shade together, trace one shadow ray together; a lane whose path ended regenerates the next
-//    sample of its pixel at the top of the next iteration.  Alternatives built and measured on MI355X:
+//  * inside a wave the path loop is a lock-step state machine: every iteration all 64 lanes regenerate (those without a path),
+//    trace together — ONE cooperative traversal for the closest-hit rays and the pending light connections —, run the FRONT
+//    of their vertex together (emission, throughput, Russian roulette); a path that goes on is written to the wave's own queue
+//    in global memory (80 B) and frees its lane, and whenever 64 paths wait one pass runs the rest of the vertex — surface,
+//    frames, BSDF sample, light connection — for a FULL wave (round 3: the tail queue, pt_kernel.hpp PT_TAILQ; before it a third
+//    of the lanes idled through that tail and a minority material's branch ran in every iteration).  Alternatives built and measured on MI355X:
 //    a lane pool with vote-driven batched shading (516 vs 654 Msamples/s), one merged shadow+closest traversal loop
 //    per iteration (670 vs 851), packed-f32 slab tests (-5 %): slower.  Persistent traversal with dynamic ray fetch
 //    (experiments/probe_intersect_dyn.inc, wave-local ray batches): 1.16-1.55x on the stand-alone traversal kernel for
