@@ -2,10 +2,13 @@
 // Restatement of renderer/src/renderer.rs, renderer/src/renderer/{base_renderer,common,
 // pt_renderer,nee_renderer,mis_renderer}.rs and renderer/src/{camera,filter,sensor,tone_map}.rs.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include "o_materials.hpp"
 #include "o_sampler.hpp"
 
 namespace oracle {
+static thread_local bool g_trace_on = false;
 
 enum Strategy : uint32_t { STRAT_PT = 0, STRAT_NEE = 1, STRAT_MIS = 2 };
 
@@ -152,6 +155,8 @@ struct PathTracer {
         MaterialEval me{scene, c};
         me.mc_key = mc_key;   // same inner Monte-Carlo stream as the vertex's sample() call
         SS f = me.evaluate(mat, wl, wo, wi, spt);
+        if (g_trace_on) std::fprintf(stderr, "[oracle] nee wo=(%.9g %.9g %.9g) wi=(%.9g %.9g %.9g) f0=%.9g pdf_dir=%.9g pdf_bsdf=%.9g rad0=%.9g\n", wo.x, wo.y, wo.z, wi.x, wi.y, wi.z,
+                                     f.v[0], rad.pdf_dir, me.pdf(mat, wl, wo, wi, spt), rad.radiance.v[0]);
         float distance2 = length_squared(dv);
         V3 ln = transform_normal(r2t, rad.light_normal);
         float cos_light = std::fabs(dot(ln, -wi));
@@ -232,6 +237,10 @@ struct PathTracer {
     SS trace(uint32_t px, uint32_t py, uint32_t sample_index, Wavelengths* wl_out, Counters* c, uint32_t* flags = nullptr) const {
         Sampler smp = Sampler::create((int)prm.sampler, prm.spp, prm.width, prm.height, prm.seed);
         smp.start_pixel_sample(px, py, sample_index, prm.width);
+        if (const char* tr = std::getenv("PTORACLE_TRACE")) {   // "x,y,s": print the light connections of that sample (debugging aid)
+            unsigned tx = 0, ty = 0, ts = 0;
+            g_trace_on = std::sscanf(tr, "%u,%u,%u", &tx, &ty, &ts) == 3 && tx == px && ty == py && ts == sample_index;
+        }
         SS T = SS::one(), L = SS::zero();
         float u = smp.get_1d();
         Wavelengths wl = Wavelengths::new_uniform(u);
@@ -259,6 +268,8 @@ struct PathTracer {
             // key of the clearcoat's inner Monte-Carlo stream: one stream per path vertex (see McRng)
             me.mc_key = mix_bits((((uint64_t)smp.morton_index) << 32) | (uint64_t)smp.dimension) ^ 0xD1B54A32D192ED03ull;
             MaterialSample ms = me.sample(mat, uc, uv, wl, wo, spt);
+            if (g_trace_on) std::fprintf(stderr, "[oracle] sample depth=%u sampled=%d spec=%d wo=(%.9g %.9g %.9g) wi=(%.9g %.9g %.9g) f0=%.9g pdf=%.9g uc=%.9g uv=(%.9g %.9g) T0=%.9g\n", depth - 1, (int)ms.is_sampled,
+                                         (int)ms.is_specular(), wo.x, wo.y, wo.z, ms.wi.x, ms.wi.y, ms.wi.z, ms.f.v[0], ms.pdf, uc, uv.x, uv.y, T.v[0]);
             if (ms.is_non_specular() && prm.strategy != STRAT_PT) {                         // base_renderer.rs:218-228
                 LightSampler ls(scene, wl);                                                 // mis_renderer.rs:40
                 float ul = smp.get_1d();

@@ -15,7 +15,10 @@ for sid, strat in pairs:
     for slack in (0.0, 1e-5):
         pair = {}
         for name, be in (("gpu", prod), ("cpu", orc)):
-            sc = be.new_scene(); pair[name] = (sc, pkg.scenes.load_scene(sc, sid, 64, 48, tex_size=128))
+            sc = be.new_scene()
+            if name == "cpu" and os.environ.get("ORACLE_RENDER_LOWERING") == "1":
+                orc.set_render_space_lowering(sc, True)      # diagnostic: the oracle intersects pre-transformed triangles like the product
+            pair[name] = (sc, pkg.scenes.load_scene(sc, sid, 64, 48, tex_size=128))
         orc.set_faithful(pair["cpu"][0], False)
         prm = pkg.make_params(64, strat, "sobol", rr_gate_slack=slack)
         g = prod.render(pair["gpu"][0], pair["gpu"][1], prm); c = orc.render(pair["cpu"][0], pair["cpu"][1], prm)

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""ad-hoc: which samples of a 64x48x64 frame differ between GPU and oracle, where on the frame, at which first depth"""
+import importlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+pkg = importlib.import_module("toy-cpu-pathtracing_amd")
+import ptoracle
+prod, orc = pkg.Product(), ptoracle.Oracle()
+sid, strat = int(sys.argv[1]), sys.argv[2]
+W, H, S = 64, 48, 64
+ys, xs, ss = np.meshgrid(np.arange(H), np.arange(W), np.arange(S), indexing="ij")
+xys = np.stack([xs.ravel(), ys.ravel(), ss.ravel()], 1).astype(np.uint32)
+gsc = prod.new_scene(); gcam = pkg.scenes.load_scene(gsc, sid, W, H, tex_size=128)
+osc = orc.new_scene()
+if os.environ.get("ORACLE_RENDER_LOWERING") == "1": orc.set_render_space_lowering(osc, True)
+ocam = pkg.scenes.load_scene(osc, sid, W, H, tex_size=128); orc.set_faithful(osc, False)
+first = np.zeros(xys.shape[0], np.int32)
+for d in list(range(1, 9)) + [16]:
+    prm = pkg.make_params(S, strat, "sobol", max_depth=d)
+    Lg, lg, pg = gsc.probe_radiance(gcam, prm, xys)
+    Lc, lc, pc = osc.probe_radiance(ocam, prm, xys)
+    with np.errstate(invalid="ignore"):
+        bad = ~np.all((np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4) | (np.isnan(Lg) & np.isnan(Lc)), axis=1)
+    first[(first == 0) & bad] = d
+    if True:
+        idx = np.nonzero(bad & (first == d))[0][:4]
+        for i in idx:
+            print("depth", d, "xys", xys[i].tolist(), "gpu", Lg[i].tolist(), "cpu", Lc[i].tolist(), "pdf", pg[i].tolist(), pc[i].tolist())
+print("share", float((first > 0).mean()), "first-depth hist", dict(zip(*[a.tolist() for a in np.unique(first[first > 0], return_counts=True)])))
+img = np.zeros((H, W), int)
+np.add.at(img, (xys[first > 0, 1], xys[first > 0, 0]), 1)
+for y in range(H):
+    print("".join(" .:*#@"[min(5, v)] for v in img[y]))

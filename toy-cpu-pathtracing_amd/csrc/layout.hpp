@@ -106,18 +106,31 @@ struct alignas(16) DevTriShade {
     uint32_t light;                // light index if emissive else ~0
     uint32_t local_tri;            // triangle index inside its mesh
     float light_pdf_area;          // (1/area_i) * (cdf_i - cdf_{i-1}) for emissive tris (emissive_triangle_mesh.rs:334-353)
-    float ng[3]; uint32_t pad_ng;  // RENDER-space geometric normal, normalize(normalize(cross(p1-p0, p2-p0))) (ray.rs:167-174): a function of
+    float ng[3]; uint32_t pad_ng;  // LOCAL-space geometric normal, normalize(normalize(cross(p1-p0, p2-p0))) (ray.rs:167-174): a function of
                                    // the triangle alone, computed once by the host with the arithmetic of the device code it replaces
 };
 static_assert(sizeof(DevTriShade) == 112, "shade record must be 112 B");
 
-struct alignas(16) DevInstance {
-    float lin[9];      // linear part of local_to_render, column-major 3x3 (vectors)
-    float nrm[9];      // inverse-transpose of lin, column-major 3x3 (normals)
-    uint32_t identity; // 1: both are the identity, skip the multiplies
-    uint32_t pad;
+// The reference intersects every mesh in ITS OWN space: the ray goes through local_to_render.inverse() (a numeric Mat4 inverse, per call),
+// the hit comes back through local_to_render (primitive/impls/triangle_mesh.rs:89-119, samples.rs:130-143).  Position, normals and even wo
+// (= M * -(M^-1 * d)) therefore carry the roundings of that round trip, and rough GGX lobes / the Russian-roulette gate amplify their
+// last bit into other paths.  The traversal walks render-space triangles (DevTri); the ONE triangle it returns is intersected again the
+// reference's way (refine_hit, pt_path.hpp) with this record and the instance's two matrices, so that the shading point is the
+// reference's bit for bit.
+struct alignas(16) DevTriLocal {
+    float p0[3]; float p1x;        // LOCAL-space positions in the mesh's own vertex order
+    float p1yz[2]; float p2xy[2];
+    float p2z; uint32_t instance; uint32_t pad[2];   // pad[0]: DevInstance::identity of that instance (known before the instance record is read); pad[1] = DevTri::pad[0]
 };
-static_assert(sizeof(DevInstance) == 80, "instance record");
+static_assert(sizeof(DevTriLocal) == 48, "local tri must be 48 B");
+
+struct alignas(16) DevInstance {
+    float m[12];       // local_to_render: columns x, y, z, w (the xyz of each; the bottom row is 0 0 0 1)
+    float inv[12];     // glam Mat4::inverse(local_to_render), same layout (scene.cpp mat4_inverse_glam)
+    uint32_t identity; // 1: the 3x3 parts of both are exactly the identity (a translation): the multiplies are exact and skipped
+    uint32_t pad[3];
+};
+static_assert(sizeof(DevInstance) == 112, "instance record");
 
 enum : uint32_t { SPK_CONSTANT = 0, SPK_SIGMOID = 1, SPK_LUT = 2, SPK_TEXTURE = 3, SPK_ILLUM = 4 };   // ILLUM: pad[0] = scale bits, id = illuminant LUT
 struct DevTexture {
@@ -201,6 +214,7 @@ struct DevScene {
     float grid_org[3], grid_cell[3];   // plane = grid_org + q * grid_cell
     const DevTri* tris;
     const DevTriShade* shade;
+    const DevTriLocal* tris_local; // leaf order, like tris / shade
     const DevInstance* instances;
     const DevMaterial* materials;
     const DevLight* lights;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "layout.hpp"
+#include "pt_libm.hpp"
 
 namespace pt {
 
@@ -13,6 +14,17 @@ namespace pt {
 
 struct f3 { float x, y, z; };
 struct f2 { float x, y; };
+// sin / cos as the reference's host computes them (pt_libm.hpp: glibc's algorithm in double, bit for bit); PT_LIBM_EXACT 0 = the device libm
+#ifndef PT_LIBM_EXACT
+#define PT_LIBM_EXACT 1
+#endif
+PT_DEV void ref_sincosf(float x, float* sn, float* cs) {
+#if PT_LIBM_EXACT
+    if (ptlibm::sincosf_glibc(x, sn, cs)) return;
+#endif
+    sincosf(x, sn, cs);
+}
+PT_DEV float ref_sinf(float x) { float s, c; ref_sincosf(x, &s, &c); return s; }
 PT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 PT_DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 PT_DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -508,6 +520,71 @@ PT_DEV RaySetup setup_ray(f3 rd) {
 
 struct Hit { float t, b0, b1, b2; uint32_t tri; uint32_t mclass; };   // mclass: the sort class of the triangle's material (DevTri::pad[0]: MT_* | 8 if it has a spectrum texture), filled by trace_pair_coop
 
+
+// ---- the reference's per-primitive lowering (primitive/impls/triangle_mesh.rs:89-119) ----
+// glam Mat4::transform_point3 / transform_vector3 on the 3x4 part of a matrix held as its four columns' xyz
+struct InstXf { f3 mx, my, mz, mw, ix, iy, iz, iw; bool identity; };
+PT_DEV InstXf load_instance(const DevInstance* di) {
+    const float4* q = (const float4*)di;
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
+    InstXf x;
+    x.mx = mk3(a.x, a.y, a.z); x.my = mk3(a.w, b.x, b.y); x.mz = mk3(b.z, b.w, c.x); x.mw = mk3(c.y, c.z, c.w);
+    x.ix = mk3(d.x, d.y, d.z); x.iy = mk3(d.w, e.x, e.y); x.iz = mk3(e.z, e.w, f.x); x.iw = mk3(f.y, f.z, f.w);
+    x.identity = __float_as_uint(g.x) != 0u;
+    return x;
+}
+PT_DEV f3 xf_vector(f3 cx, f3 cy, f3 cz, f3 v) { f3 r = cx * v.x; r = r + cy * v.y; r = r + cz * v.z; return r; }
+PT_DEV f3 xf_point(f3 cx, f3 cy, f3 cz, f3 cw, f3 p) { f3 r = cx * p.x; r = r + cy * p.y; r = r + cz * p.z; r = r + cw; return r; }
+// Transform * Normal (math/src/transform.rs:45-51): transpose(inverse) * n, renormalised by Normal::from
+PT_DEV f3 xf_normal(const InstXf& x, f3 n) {
+    return normalize(xf_vector(mk3(x.ix.x, x.iy.x, x.iz.x), mk3(x.ix.y, x.iy.y, x.iz.y), mk3(x.ix.z, x.iy.z, x.iz.z), n));
+}
+PT_DEV TriVerts load_tri_local(const DevTriLocal* tris, uint32_t i, uint32_t* instance, bool* identity, uint32_t* mclass = nullptr) {
+    const float4* q = (const float4*)(tris + i);
+    const float4 a = q[0], b = q[1], c = q[2];
+    *instance = __float_as_uint(c.y);
+    *identity = __float_as_uint(c.z) != 0u;                               // DevTriLocal::pad[0]: the instance is a translation (DevInstance::identity)
+    if (mclass) *mclass = __float_as_uint(c.w);                           // DevTriLocal::pad[1] = DevTri::pad[0]: sort class of the triangle's material
+    return TriVerts{mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x)};
+}
+// the translation columns alone (one 16-byte load each): all an identity instance needs
+PT_DEV f3 load_instance_mw(const DevInstance* di) { const float4 c = ((const float4*)di)[2]; return mk3(c.y, c.z, c.w); }
+PT_DEV f3 load_instance_iw(const DevInstance* di) { const float4 f = ((const float4*)di)[5]; return mk3(f.y, f.z, f.w); }
+
+// PT_EXACT_HIT 1 (default): the triangle the render-space traversal returned is intersected once more the way the reference does it - the
+// ray carried into the mesh's local space by the numeric inverse of local_to_render, the watertight test on the mesh's own vertices —
+// and the hit's barycentrics are replaced by that test's.  load_surface then builds position, normals and wo from LOCAL data through
+// local_to_render, operation for operation (samples.rs:130-143), so the shading point equals the reference's bit for bit (measured: with
+// this, exact GGX terms, libm's sin / cos and the numeric frame inverse every scene's frames equal the faithful oracle's to 1e-7 with the
+// reference's own Russian-roulette gate).  If the local test rejects the triangle (an edge decided the other way by
+// rounding: the reference would have hit a neighbour), the render-space barycentrics stay: one sample, an ulp off.
+#ifndef PT_EXACT_HIT
+#define PT_EXACT_HIT 1
+#endif
+// The barycentrics of the triangle a closest-hit traversal found (its last step: every traversal ends here).
+//   PT_EXACT_HIT 0: the render-space test once more (same function, same inputs as inside the traversal);
+//   PT_EXACT_HIT 1: the reference's test - local ray, local vertices; the render-space test only if that one rejects the triangle.
+PT_DEV void winner_hit(const DevScene& sc, f3 ro, f3 rd, const RaySetup& rs, uint32_t tri, Hit& hit) {
+    float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+    hit.tri = tri;
+#if PT_EXACT_HIT
+    uint32_t inst; bool ident;
+    const TriVerts tl = load_tri_local(sc.tris_local, tri, &inst, &ident, &hit.mclass);
+    f3 ol, dl;
+    if (ident) { ol = ro + load_instance_iw(sc.instances + inst); dl = rd; }   // 1 * a + 0 * b + 0 * c is a: the multiplies are exact
+    else { const InstXf x = load_instance(sc.instances + inst); ol = xf_point(x.ix, x.iy, x.iz, x.iw, ro); dl = xf_vector(x.ix, x.iy, x.iz, rd); }
+    const RaySetup ls = setup_ray(dl);
+    if (!intersect_triangle(ol, dl, ls.kx, ls.ky, ls.kz, ls.sx, ls.sy, ls.sz, 3.402823466e+38f, tl, t, b0, b1, b2))
+#else
+    (void)0;
+#endif
+    {
+        const TriVerts tv = load_tri(sc.tris, tri, &hit.mclass);
+        intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
+    }
+    hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+}
+
 // Closest hit (Scene::intersect, scene.rs:80-90).  One flat BVH2; the far child goes to this lane's LDS stack
 // (stack[depth*64 + lane]: consecutive lanes hit consecutive banks, no conflicts); t_best prunes both
 // boxes and triangles, ties keep the first triangle found.
@@ -558,6 +635,7 @@ PT_DEV bool trace_closest(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_
         if (sp == 0) break;
         --sp; cur = (int32_t)stack[sp * 64];
     }
+    if (PT_EXACT_HIT && found) winner_hit(sc, ro, rd, rs, hit.tri, hit);
     if (STATS && found) st.closest_hits++;
     return found;
 }
@@ -1075,11 +1153,8 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
     const unsigned long long key = L.best[lane];
     const uint32_t tri = (uint32_t)key;
     const bool found = want && tri != 0xffffffffu;
-    if (found) {                                                             // the winner's barycentrics: same function, same inputs
-        TriVerts tv = load_tri(sc.tris, tri);
-        float t, b0, b1, b2;
-        intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
-        hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = tri;
+    if (found) {                                                             // the winner's barycentrics
+        winner_hit(sc, ro, rd, rs, tri, hit);
         if (STATS) st.closest_hits++;
     }
     return found;
@@ -1365,12 +1440,8 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
     const unsigned long long key = L.best[lane];
     const uint32_t tri = (uint32_t)key;
     c_found = c_want && !inflight && tri != 0xffffffffu;
-    if (c_found) {                                                           // the winner's barycentrics: same function, same inputs
-        uint32_t mclass;
-        TriVerts tv = load_tri(sc.tris, tri, &mclass);
-        float t, b0, b1, b2;
-        intersect_triangle(c_ro, c_rd, crs.kx, crs.ky, crs.kz, crs.sx, crs.sy, crs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
-        hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = tri; hit.mclass = mclass;
+    if (c_found) {                                                           // the winner's barycentrics
+        winner_hit(sc, c_ro, c_rd, crs, tri, hit);
         if (STATS) st.closest_hits++;
     }
 }

@@ -14,22 +14,43 @@ PT_DEV float cos_phi(f3 w) { float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f)); re
 PT_DEV float sin_phi(f3 w) { float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f)); return st == 0.0f ? 0.0f : fminf(fmaxf(w.y / st, -1.0f), 1.0f); }
 
 // Every material of the reference passes alpha_x == alpha_y (glass_material.rs:120-126, metal_material.rs, the clearcoat layers).
-// The anisotropic expressions then reduce to tan^2(theta) (cos^2(phi) + sin^2(phi)) / alpha^2 with cos(phi) = x / sin(theta),
-// sin(phi) = y / sin(theta): numerically that is (x^2 + y^2) / (z^2 alpha^2) — the (1 - z^2) of tan^2 and the sin^2(theta) under cos / sin
-// cancel, rounding error included.  The isotropic forms below compute exactly that quotient, so they stay within a few ulp of the
-// reference everywhere (using (1 - z^2) / z^2 instead drifts by up to 1e-4 near the normal, where 1 - z^2 cancels: enough to flip
-// Russian-roulette decisions in 4e-4 of the samples of a rough-metal scene), and save the two sqrt + two divisions of cos_phi / sin_phi
-// per evaluation (the coat albedo alone evaluates D and two Lambdas 64 times per vertex).
+// The anisotropic expressions then reduce ALGEBRAICALLY to (x^2 + y^2) / (z^2 alpha^2): the (1 - z^2) of tan^2 and the sin^2(theta) under
+// cos / sin cancel, rounding error included — unless cos_phi / sin_phi CLAMP.  Near the normal 1 - z^2 is a difference of two numbers next
+// to 1 (z^2 = 1 - 1.5e-6 has a spacing of 6e-8: 4 % of the result); when the rounded value comes out smaller than x^2, x / sin(theta) > 1 is
+// clamped to 1 and the error no longer cancels: the reference's D then differs from the algebraic form by up to several per cent.  For a
+// near-mirror metal (alpha = 0.0025: e = tan^2 / alpha^2 of order 1 at theta = 1e-3) that is a 1 ... 6 % step in f or pdf of a sampled
+// direction, the throughput f / pdf lands on the other side of 1, the Russian-roulette gate draws (or not) and the path parts from the
+// reference's (measured: 0.04 % of the samples of scene 7, round 3).  PT_GGX_EXACT = 1 (default) therefore restates the reference's
+// expressions operation for operation; 0 keeps the algebraic forms of rounds 1-2 (two sqrt and four divisions fewer per D + Lambda).
+#ifndef PT_GGX_EXACT
+#define PT_GGX_EXACT 1
+#endif
 PT_DEV float tan2_theta_xy(f3 w) { float c2 = w.z * w.z; return c2 == 0.0f ? INFINITY : (w.x * w.x + w.y * w.y) / c2; }
-PT_DEV float ggx_D(float ax, float ay, f3 wm) {                                   // generalized_schlick.rs:119-131
-    if (!isfinite(tan2_theta(wm))) return 0.0f;
+PT_DEV float ggx_D(float ax, float ay, f3 wm) {                                   // dielectric.rs:35-47 = generalized_schlick.rs:119-131
+    const float t2 = tan2_theta(wm);
+    if (!isfinite(t2)) return 0.0f;
     float c2 = wm.z * wm.z, c4 = c2 * c2;
+#if PT_GGX_EXACT
+    const float st = sqrtf(fmaxf(1.0f - c2, 0.0f));
+    const float cp = st == 0.0f ? 1.0f : fminf(fmaxf(wm.x / st, -1.0f), 1.0f), sp = st == 0.0f ? 0.0f : fminf(fmaxf(wm.y / st, -1.0f), 1.0f);
+    float e = t2 * ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay));
+#else
     float e = tan2_theta_xy(wm) / (ax * ay);
+#endif
     return 1.0f / (PI_F * ax * ay * c4 * ((1.0f + e) * (1.0f + e)));
 }
-PT_DEV float ggx_lambda(float ax, float ay, f3 w) {                               // :132-140
-    if (isinf(tan2_theta(w))) return 0.0f;
+PT_DEV float ggx_lambda(float ax, float ay, f3 w) {                               // dielectric.rs:50-58 = :132-140
+    const float t2 = tan2_theta(w);
+    if (isinf(t2)) return 0.0f;
+#if PT_GGX_EXACT
+    const float st = sqrtf(fmaxf(1.0f - w.z * w.z, 0.0f));
+    const float cp = st == 0.0f ? 1.0f : fminf(fmaxf(w.x / st, -1.0f), 1.0f), sp = st == 0.0f ? 0.0f : fminf(fmaxf(w.y / st, -1.0f), 1.0f);
+    const float a = cp * ax, b = sp * ay;
+    const float alpha2 = a * a + b * b;
+    return (sqrtf(1.0f + alpha2 * t2) - 1.0f) / 2.0f;
+#else
     return (sqrtf(1.0f + (ax * ay) * tan2_theta_xy(w)) - 1.0f) / 2.0f;
+#endif
 }
 PT_DEV float ggx_G(float ax, float ay, f3 wo, f3 wi) { return 1.0f / (1.0f + ggx_lambda(ax, ay, wo) + ggx_lambda(ax, ay, wi)); }
 PT_DEV float ggx_Dw(float ax, float ay, f3 w, f3 wm) {                            // :154-164
@@ -48,7 +69,7 @@ PT_DEV f3 ggx_sample_wm(float ax, float ay, f3 w, f2 u) {                       
     f3 t2 = cross(wh, t1);
     float r = sqrtf(u.x), th = 2.0f * PI_F * u.y;
     float cs_th, sn_th;
-    if (SINCOS) sincosf(th, &sn_th, &cs_th); else { cs_th = cosf(th); sn_th = sinf(th); }
+    (void)SINCOS; ref_sincosf(th, &sn_th, &cs_th);
     float px = r * cs_th, pyy = r * sn_th;
     float h = sqrtf(fmaxf(1.0f - px * px, 0.0f));
     float lf = (1.0f + wh.z) / 2.0f;
@@ -76,7 +97,8 @@ PT_DEV float fresnel_complex1(float cos_i, float eta, float k) {
     Cplx a{1.0f - s2t.re, 0.0f - s2t.im};
     float r = sqrtf(a.re * a.re + a.im * a.im), theta = atan2f(a.im, a.re);
     float sr = sqrtf(r), ht = theta * 0.5f;
-    Cplx ct{sr * cosf(ht), sr * sinf(ht)};
+    float sn_ht, cs_ht; ref_sincosf(ht, &sn_ht, &cs_ht);
+    Cplx ct{sr * cs_ht, sr * sn_ht};
     Cplx ec{ce.re * cos_i, ce.im * cos_i};
     Cplx rp = cdiv(Cplx{ec.re - ct.re, ec.im - ct.im}, Cplx{ec.re + ct.re, ec.im + ct.im});
     Cplx et = cmul(ce, ct);

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void probe_intersect_kernel(DevScene sc, const 
     Hit h{};
     f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     if (trace_closest<false>(sc, ro, rd, 3.402823466e+38f, s_stack + threadIdx.x, h, st)) {
-        Surface sf = load_surface(sc, h);
+        Surface sf = load_surface(sc, h, rd);
         const float4* q = (const float4*)(sc.shade + h.tri);
         float4 e = q[4], f = q[5];
         out_t[i] = h.t; out_inst[i] = __float_as_uint(e.w); out_tri[i] = __float_as_uint(f.z);

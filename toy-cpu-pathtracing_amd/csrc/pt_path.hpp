@@ -34,7 +34,7 @@ PT_DEV Frame shading_frame(f3 shading_normal, f3 tangent) {
 // a fifth of the flips has yet another source.  Cost: -1.2...-1.3 % on the dielectric kernels (scenes 8 / 9 / 10), -5.7 % on C2's kernel if
 // applied everywhere.  It does not by itself let the solid-plastic frames pass with the reference's gate, so it is not the default.
 #ifndef PT_FRAME_INVERSE
-#define PT_FRAME_INVERSE 0
+#define PT_FRAME_INVERSE 2
 #endif
 template <uint32_t FEAT> constexpr bool numeric_frames() { return PT_FRAME_INVERSE == 2 || (PT_FRAME_INVERSE == 1 && (FEAT & FEAT_DIEL) != 0u); }
 // glam Mat4::inverse of the matrix with columns c0, c1, c2 (and w = (0, 0, 0, 1)): the inverse's columns
@@ -74,22 +74,23 @@ PT_DEV f3 generate_tangent(f3 n) { return orthogonalize(n, fabsf(n.x) > 0.999f ?
 
 struct Surface {           // SurfaceInteraction<Render> + what the integrator needs
     f3 p, ng, ns, tangent;
+    f3 wo;                 // Intersection.wo: local_to_render * -(render_to_local * d), the ray direction after the reference's round trip
     f2 uv;
     uint32_t material, flags, light;
     float light_pdf_area;
 };
 
-PT_DEV Surface load_surface(const DevScene& sc, const Hit& h) {
+PT_DEV Surface load_surface(const DevScene& sc, const Hit& h, f3 rd) {
     Surface s;
-    TriVerts tv = load_tri(sc.tris, h.tri);
-    s.p = tv.p0 * h.b0 + tv.p1 * h.b1 + tv.p2 * h.b2;                               // ray.rs:161-165
+    uint32_t inst; bool ident;
+    const TriVerts tv = load_tri_local(sc.tris_local, h.tri, &inst, &ident);
+    const f3 p_l = tv.p0 * h.b0 + tv.p1 * h.b1 + tv.p2 * h.b2;                       // ray.rs:161-165, in LOCAL space
     const float4* q = (const float4*)(sc.shade + h.tri);
     float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
-    s.ng = mk3(g.x, g.y, g.z);                                                       // ray.rs:167-174, precomputed per triangle (layout.hpp)
+    const f3 ng_l = mk3(g.x, g.y, g.z);                                              // ray.rs:167-174, precomputed per triangle (layout.hpp)
     f3 n0 = mk3(a.x, a.y, a.z), n1 = mk3(a.w, b.x, b.y), n2 = mk3(b.z, b.w, c.x);
     f3 tan_l = mk3(c.y, c.z, c.w);
     s.material = __float_as_uint(e.z);
-    uint32_t inst = __float_as_uint(e.w);
     s.flags = __float_as_uint(f.x); s.light = __float_as_uint(f.y); s.light_pdf_area = f.w;
     // geometry/impls/triangle_mesh.rs:73-97 in LOCAL space, then primitive transform (samples.rs:130-143)
     f3 sn_l = normalize(n0 * h.b0 + n1 * h.b1 + n2 * h.b2);
@@ -101,12 +102,16 @@ PT_DEV Surface load_surface(const DevScene& sc, const Hit& h) {
         s.uv = f2{0.0f, 0.0f};
         tg_l = generate_tangent(sn_l);
     }
-    const DevInstance* di = sc.instances + inst;
-    if (s.flags & 4u) {                                                              // identity linear part: known from the shade record, no dependent load
-        s.ns = normalize(sn_l); s.tangent = tg_l;
+    if (ident) {                                                                     // a translation: the 3x3 products are exact
+        s.p = p_l + load_instance_mw(sc.instances + inst);
+        s.ng = normalize(ng_l); s.ns = normalize(sn_l); s.tangent = tg_l;
+        s.wo = -rd;
     } else {
-        s.ns = normalize(mat3_mul(di->nrm, sn_l));
-        s.tangent = mat3_mul(di->lin, tg_l);
+        const InstXf x = load_instance(sc.instances + inst);
+        s.p = xf_point(x.mx, x.my, x.mz, x.mw, p_l);
+        s.ng = xf_normal(x, ng_l); s.ns = xf_normal(x, sn_l);
+        s.tangent = xf_vector(x.mx, x.my, x.mz, tg_l);
+        s.wo = xf_vector(x.mx, x.my, x.mz, -xf_vector(x.ix, x.iy, x.iz, rd));
     }
     return s;
 }
@@ -165,7 +170,7 @@ PT_DEV float env_pdf(const DevEnv& e, f3 dir_render) {                          
     uint32_t x = min((uint32_t)floorf(u * (float)w), w - 1), y = min((uint32_t)floorf(v * (float)h), h - 1);
     float4 p = ((const float4*)e.texels)[(size_t)y * w + x];
     float lum = 0.299f * p.x + 0.587f * p.y + 0.114f * p.z;
-    float st = fmaxf(sinf(theta), 1e-8f);
+    float st = fmaxf(ref_sinf(theta), 1e-8f);
     float pdf_tex = (lum * st) / e.total_weight;
     float jac = (float)w * (float)h / (2.0f * PI_F * PI_F * st);
     return pdf_tex * jac;
@@ -181,7 +186,7 @@ PT_DEV void env_sample(const DevEnv& e, f2 uv, f3& wi, float& pdf_dir) {        
     uint32_t x = env_sample_cdf(e.conditional + (size_t)y * w, w, uv.y);
     float u = ((float)x + 0.5f) / (float)w, v = ((float)y + 0.5f) / (float)h;
     float theta = v * PI_F, phi = u * 2.0f * PI_F;
-    float s_t, c_t, s_p, c_p; sincosf(theta, &s_t, &c_t); sincosf(phi, &s_p, &c_p);
+    float s_t, c_t, s_p, c_p; ref_sincosf(theta, &s_t, &c_t); ref_sincosf(phi, &s_p, &c_p);
     f3 wl = mk3(s_t * c_p, c_t, s_t * s_p);
     wi = mat3_mul(e.l2r, wl);
     pdf_dir = env_pdf(e, wi);
@@ -353,8 +358,8 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
         Surface sf; const DevMaterial* mat = nullptr; uint32_t mtype;
         if (PHASE == 1) {
             mtype = hit.mclass & 7u;
-            if (mtype == MT_EMISSIVE) { sf = load_surface(sc, hit); mat = sc.materials + sf.material; }
-        } else { sf = load_surface(sc, hit); mat = sc.materials + sf.material; mtype = mat->type; }
+            if (mtype == MT_EMISSIVE) { sf = load_surface(sc, hit, rd); mat = sc.materials + sf.material; }
+        } else { sf = load_surface(sc, hit, rd); mat = sc.materials + sf.material; mtype = mat->type; }
         const bool emissive = PHASE != 2 && mtype == MT_EMISSIVE;            // (PHASE 2: the path went on, so the surface is not an emitter)
         float Le[4] = {0, 0, 0, 0};
         if constexpr (PHASE != 2) {
@@ -458,7 +463,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             if constexpr (numeric_frames<FEAT>()) shading_frames_numeric(sf.ns, sf.tangent, fr, fw_num);
             else fr = shading_frame(sf.ns, sf.tangent);
             const Frame& fw = numeric_frames<FEAT>() ? fw_num : fr;           // (the transpose form has ONE matrix: no second copy in ShadeCtx)
-            f3 wo_r = -rd;                                                    // Intersection.wo
+            f3 wo_r = sf.wo;                                                  // Intersection.wo
             f3 wo = to_local(fr, wo_r);
             f3 ng_t = normalize(to_local(fw, sf.ng));                         // Transform * Normal: inverse-transpose, then renormalised
             // base_renderer.rs:212-213 draws uc then uv for every material.  A draw whose value the material
@@ -494,7 +499,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             }
             f3 wo_nm = to_local(nf, wo);
             // ---- hand-over to the second half ----
-            C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; if constexpr (numeric_frames<FEAT>()) C.fw = fw_num; C.nf = nf; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
+            C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; if constexpr (numeric_frames<FEAT>() && !(FEAT & FEAT_CC)) C.fw = fw_num; C.nf = nf; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
             C.geo_wo = dot(ng_t, wo); C.uc = uc; C.uv = uv; C.is_diel = is_diel; C.rough_diel = rough_diel; C.d_alpha = d_alpha; C.cont = true;
             if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) {
                 // SimpleClearcoatPbrMaterial: FloatParameter values at the shading point + the inputs of the coat's directional albedo
@@ -537,7 +542,12 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
     bool& do_shadow = sh.on; f3& sh_o = sh.o; f3& sh_d = sh.d; float& sh_t = sh.t; float* sh_c = sh.c;
     (void)L; (void)from_camera;
     const Surface& sf = C.sf; const DevMaterial* mat = C.mat; const uint32_t mtype = C.mtype;
-    const Frame& fr = C.fr; const Frame& fw = numeric_frames<FEAT>() ? C.fw : C.fr; const Frame& nf = C.nf; const f3 wo = C.wo, wo_nm = C.wo_nm, ng_t = C.ng_t;
+    // (clearcoat kernels: ShadeCtx crosses the cooperative albedo estimate between the halves; the way back is recomputed here from the
+    //  way there — the same inverse of the same matrix — instead of holding nine more registers across it: +3 % on scene 17)
+    Frame fw_re;
+    if constexpr (numeric_frames<FEAT>() && (FEAT & FEAT_CC) != 0u)
+        inverse3_glam(mk3(C.fr.t.x, C.fr.b.x, C.fr.n.x), mk3(C.fr.t.y, C.fr.b.y, C.fr.n.y), mk3(C.fr.t.z, C.fr.b.z, C.fr.n.z), fw_re.t, fw_re.b, fw_re.n);
+    const Frame& fr = C.fr; const Frame& fw = numeric_frames<FEAT>() ? ((FEAT & FEAT_CC) ? fw_re : C.fw) : C.fr; const Frame& nf = C.nf; const f3 wo = C.wo, wo_nm = C.wo_nm, ng_t = C.ng_t;
     const float uc = C.uc; const f2 uv = C.uv; const bool is_diel = C.is_diel, rough_diel = C.rough_diel;
     {
         {
@@ -561,7 +571,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                 eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, cs, wl, sf.uv, albedo, st);
                 if (wo_nm.z != 0.0f) {
                     float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                    float sn_th, cs_th; sincosf(th, &sn_th, &cs_th);                 // one range reduction for both (same values as sinf / cosf)
+                    float sn_th, cs_th; ref_sincosf(th, &sn_th, &cs_th);             // one range reduction for both (same values as sinf / cosf)
                     f3 wi = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
                     if (wo_nm.z < 0.0f) wi.z = -wi.z;
                     if (wi.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi.z)) {
@@ -579,6 +589,8 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                 float eta[4];
                 DevSpectrum es = load_spectrum(&mat->eta);
                 eval_spectrum<STATS, (FEAT & FEAT_TEX) != 0>(sc, es, wl, sf.uv, eta, st);
+                if (mtype == MT_PLASTIC) eta[1] = eta[2] = eta[3] = eta[0];   // SampledSpectrum::constant(self.eta) (plastic_material.rs:107-109): NOT sampled through the
+                                                                              // wavelengths, so all four lanes keep the value after a glass vertex terminated the secondary ones
                 bool eta_const = (eta[1] == eta[0]) && (eta[2] == eta[0]) && (eta[3] == eta[0]);
                 if (eta[0] == 0.0f) { eta[0] = eta[1] = eta[2] = eta[3] = 1.0f; eta_const = true; }   // DielectricBsdf::new :144-148
                 bool entering = geo_wo > 0.0f;
@@ -746,7 +758,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                             }
                         } else if (wo_nm.z != 0.0f) {
                             float r = sqrtf(uv.x), th = 2.0f * PI_F * uv.y;
-                            float sn_th, cs_th; sincosf(th, &sn_th, &cs_th);
+                            float sn_th, cs_th; ref_sincosf(th, &sn_th, &cs_th);
                             f3 w = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
                             if (wo_nm.z < 0.0f) w.z = -w.z;
                             if (w.z != 0.0f && sgn1(wo_nm.z) == sgn1(w.z)) {
@@ -943,6 +955,11 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     if ((FEAT & FEAT_ROUGH) && nee_kind == 3u) {                 // DielectricBsdf::{evaluate_microfacet,pdf_microfacet} (:468-645)
                         const float alpha = C.d_alpha;
                         const float es = d_er[0];
+                        // The reference connects to the light AFTER it sampled the BSDF (base_renderer.rs:203-228).  If that sample was a dispersive
+                        // transmission it terminated the secondary wavelengths, and the evaluation's eta.sample(lambda) now returns (eta0, 0, 0, 0)
+                        // (spectrum.rs:43-47): eta_rel is 0 in those lanes, their Fresnel term 1, and pr = (F0 + 3) / 4 in the pdf of the MIS weight.
+                        // (Plastic builds its eta without the wavelengths — plastic_material.rs:107-109 — and keeps all four lanes.)
+                        if (wl.term && !d_plastic) d_er[1] = d_er[2] = d_er[3] = 0.0f;
                         float co = wo_nm.z, ci = wi_nm.z;
                         bool refl = ci * co > 0.0f;
                         float etap = !refl ? (co > 0.0f ? es : 1.0f / es) : 1.0f;
@@ -1051,6 +1068,10 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     float g = fabsf(dot(ln_t, -wi_t)) / dist2;
                     float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
                     sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
+#ifdef PT_TRACE_MORTON
+                    if (smp.morton == PT_TRACE_MORTON) printf("[gpu] nee depth=%u wo=(%.9g %.9g %.9g) wi=(%.9g %.9g %.9g) f0=%.9g pdf_dir=%.9g pdf_bsdf=%.9g rad0=%.9g alpha=%.9g kind=%u\n", P.depth, wo_nm.x, wo_nm.y, wo_nm.z,
+                                                              wi_nm.x, wi_nm.y, wi_nm.z, fl[0], pdf_dir, pdf_b, lrad[0] * l_inten, C.d_alpha, nee_kind);
+#endif
                     const float rden = 1.0f / (pdf_a * lprob);   // one division for the four wavelengths (<= 1 ulp from x / (pdf_a * lprob))
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -1059,6 +1080,10 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                 }
             }
 
+#ifdef PT_TRACE_MORTON
+            if (smp.morton == PT_TRACE_MORTON) printf("[gpu] sample depth=%u sampled=%d spec=%d wo=(%.9g %.9g %.9g) wi_sh=(%.9g %.9g %.9g) f0=%.9g pdf=%.9g uc=%.9g uv=(%.9g %.9g) T0=%.9g\n", P.depth, (int)sampled, (int)specular,
+                                                      wo_nm.x, wo_nm.y, wo_nm.z, wi_sh.x, wi_sh.y, wi_sh.z, s_f[0], s_pdf, uc, uv.x, uv.y, T[0]);
+#endif
             if (!sampled) {
                 end_path = true;                                              // process_bsdf_sampling -> None (:102-104,240-253)
             } else {

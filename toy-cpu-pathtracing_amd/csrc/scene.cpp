@@ -55,6 +55,34 @@ inline bool mat3_inverse_transpose(const float* m /*col-major 3x3*/, float* o, f
     return true;
 }
 
+// glam::Mat4::inverse (the cofactor form glam inherits from GLM), operation for operation: the device multiplies rays and hits with THESE
+// floats where the reference inverts local_to_render in every intersect call (primitive/impls/triangle_mesh.rs:97,  math/src/transform.rs:159-162).
+inline void mat4_inverse_glam(const float* s, float* o) {   // column-major 4x4
+    const float m00 = s[0], m01 = s[1], m02 = s[2], m03 = s[3], m10 = s[4], m11 = s[5], m12 = s[6], m13 = s[7];
+    const float m20 = s[8], m21 = s[9], m22 = s[10], m23 = s[11], m30 = s[12], m31 = s[13], m32 = s[14], m33 = s[15];
+    const float coef00 = m22 * m33 - m32 * m23, coef02 = m12 * m33 - m32 * m13, coef03 = m12 * m23 - m22 * m13;
+    const float coef04 = m21 * m33 - m31 * m23, coef06 = m11 * m33 - m31 * m13, coef07 = m11 * m23 - m21 * m13;
+    const float coef08 = m21 * m32 - m31 * m22, coef10 = m11 * m32 - m31 * m12, coef11 = m11 * m22 - m21 * m12;
+    const float coef12 = m20 * m33 - m30 * m23, coef14 = m10 * m33 - m30 * m13, coef15 = m10 * m23 - m20 * m13;
+    const float coef16 = m20 * m32 - m30 * m22, coef18 = m10 * m32 - m30 * m12, coef19 = m10 * m22 - m20 * m12;
+    const float coef20 = m20 * m31 - m30 * m21, coef22 = m10 * m31 - m30 * m11, coef23 = m10 * m21 - m20 * m11;
+    const float fac0[4] = {coef00, coef00, coef02, coef03}, fac1[4] = {coef04, coef04, coef06, coef07}, fac2[4] = {coef08, coef08, coef10, coef11};
+    const float fac3[4] = {coef12, coef12, coef14, coef15}, fac4[4] = {coef16, coef16, coef18, coef19}, fac5[4] = {coef20, coef20, coef22, coef23};
+    const float vec0[4] = {m10, m00, m00, m00}, vec1[4] = {m11, m01, m01, m01}, vec2[4] = {m12, m02, m02, m02}, vec3[4] = {m13, m03, m03, m03};
+    const float sa[4] = {1, -1, 1, -1}, sb[4] = {-1, 1, -1, 1};
+    float inv[16];
+    for (int i = 0; i < 4; ++i) {
+        inv[i] = ((vec1[i] * fac0[i] - vec2[i] * fac1[i]) + vec3[i] * fac2[i]) * sa[i];
+        inv[4 + i] = ((vec0[i] * fac0[i] - vec2[i] * fac3[i]) + vec3[i] * fac4[i]) * sb[i];
+        inv[8 + i] = ((vec0[i] * fac1[i] - vec1[i] * fac3[i]) + vec3[i] * fac5[i]) * sa[i];
+        inv[12 + i] = ((vec0[i] * fac2[i] - vec1[i] * fac4[i]) + vec2[i] * fac5[i]) * sb[i];
+    }
+    const float d0 = s[0] * inv[0], d1 = s[1] * inv[4], d2 = s[2] * inv[8], d3 = s[3] * inv[12];
+    const float det = ((d0 + d1) + d2) + d3;
+    const float rcp = 1.0f / det;
+    for (int i = 0; i < 16; ++i) o[i] = inv[i] * rcp;
+}
+
 template <typename T>
 int upload(SceneImpl* s, const std::vector<T>& v, const T** out, std::string* err) {
     void* p = nullptr;
@@ -201,6 +229,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
 
     std::vector<DevInstance> dinst(instances.size());
     std::vector<DevTri> tris_unordered;
+    std::vector<DevTriLocal> local_unordered;
     std::vector<DevTriShade> shade_unordered;
     std::vector<BuildTri> btris;
     std::vector<DevLight> lights;
@@ -263,14 +292,15 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             }
         }
         DevInstance& di = dinst[ii];
-        di.lin[0] = l2r[0]; di.lin[1] = l2r[1]; di.lin[2] = l2r[2];
-        di.lin[3] = l2r[4]; di.lin[4] = l2r[5]; di.lin[5] = l2r[6];
-        di.lin[6] = l2r[8]; di.lin[7] = l2r[9]; di.lin[8] = l2r[10];
-        float det;
-        if (!mat3_inverse_transpose(di.lin, di.nrm, &det)) { *err = "singular instance transform"; return MI355PT_E_INVALID; }
+        float lin[9] = {l2r[0], l2r[1], l2r[2], l2r[4], l2r[5], l2r[6], l2r[8], l2r[9], l2r[10]}, nrm_unused[9], det;
+        if (!mat3_inverse_transpose(lin, nrm_unused, &det)) { *err = "singular instance transform"; return MI355PT_E_INVALID; }
+        float inv[16];
+        mat4_inverse_glam(l2r, inv);
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) { di.m[3 * c + r] = l2r[4 * c + r]; di.inv[3 * c + r] = inv[4 * c + r]; }
+        for (int k = 0; k < 12; ++k) if (!std::isfinite(di.inv[k])) { *err = "singular instance transform"; return MI355PT_E_INVALID; }
         const float idm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        di.identity = std::memcmp(di.lin, idm, sizeof(idm)) == 0 ? 1u : 0u;
-        di.pad = 0;
+        di.identity = (std::memcmp(di.m, idm, sizeof(idm)) == 0 && std::memcmp(di.inv, idm, sizeof(idm)) == 0) ? 1u : 0u;
+        di.pad[0] = di.pad[1] = di.pad[2] = 0;
         bool emissive = mat.type == MT_EMISSIVE;
         uint32_t light_index = ~0u;
         std::vector<float> area_list, area_table;
@@ -293,7 +323,6 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             V3 p[3];
             uint32_t vi[3] = {mesh.idx[3 * t], mesh.idx[3 * t + 1], mesh.idx[3 * t + 2]};
             for (int k = 0; k < 3; ++k) p[k] = xform_point(l2r, V3{mesh.pos[3 * vi[k]], mesh.pos[3 * vi[k] + 1], mesh.pos[3 * vi[k] + 2]});
-            if (det < 0.0f) { std::swap(p[1], p[2]); std::swap(vi[1], vi[2]); }   // keep the geometric normal's orientation
             DevTri dt{};
             dt.p0[0] = p[0].x; dt.p0[1] = p[0].y; dt.p0[2] = p[0].z; dt.p1x = p[1].x;
             dt.p1yz[0] = p[1].y; dt.p1yz[1] = p[1].z; dt.p2xy[0] = p[2].x; dt.p2xy[1] = p[2].y; dt.p2z = p[2].z;
@@ -312,7 +341,14 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             }
             btris.push_back(bt);
             DevTriShade sh{};
-            { V3 g = normalize(normalize(cross(p[1] - p[0], p[2] - p[0]))); sh.ng[0] = g.x; sh.ng[1] = g.y; sh.ng[2] = g.z; sh.pad_ng = 0; }
+            V3 pl[3];
+            for (int k = 0; k < 3; ++k) pl[k] = V3{mesh.pos[3 * vi[k]], mesh.pos[3 * vi[k] + 1], mesh.pos[3 * vi[k] + 2]};
+            { V3 g = normalize(normalize(cross(pl[1] - pl[0], pl[2] - pl[0]))); sh.ng[0] = g.x; sh.ng[1] = g.y; sh.ng[2] = g.z; sh.pad_ng = 0; }   // LOCAL (ray.rs:167-174)
+            DevTriLocal tl{};
+            tl.p0[0] = pl[0].x; tl.p0[1] = pl[0].y; tl.p0[2] = pl[0].z; tl.p1x = pl[1].x;
+            tl.p1yz[0] = pl[1].y; tl.p1yz[1] = pl[1].z; tl.p2xy[0] = pl[2].x; tl.p2xy[1] = pl[2].y; tl.p2z = pl[2].z;
+            tl.instance = (uint32_t)ii; tl.pad[0] = di.identity; tl.pad[1] = dt.pad[0];
+            local_unordered.push_back(tl);
             const float* n0 = &mesh.nrm[3 * vi[0]]; const float* n1 = &mesh.nrm[3 * vi[1]]; const float* n2 = &mesh.nrm[3 * vi[2]];
             sh.n0[0] = n0[0]; sh.n0[1] = n0[1]; sh.n0[2] = n0[2]; sh.n1x = n1[0];
             sh.n1yz[0] = n1[1]; sh.n1yz[1] = n1[2]; sh.n2xy[0] = n2[0]; sh.n2xy[1] = n2[1]; sh.n2z = n2[2];
@@ -383,7 +419,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     if (bvh.max_depth >= STACK_DEPTH) { *err = "BVH deeper than the traversal stack"; return MI355PT_E_INVALID; }
     std::vector<DevTri> tris(bvh.order.size());
     std::vector<DevTriShade> shade(bvh.order.size());
-    for (size_t i = 0; i < bvh.order.size(); ++i) { tris[i] = tris_unordered[bvh.order[i]]; shade[i] = shade_unordered[bvh.order[i]]; }
+    std::vector<DevTriLocal> tris_local(bvh.order.size());
+    for (size_t i = 0; i < bvh.order.size(); ++i) { tris[i] = tris_unordered[bvh.order[i]]; shade[i] = shade_unordered[bvh.order[i]]; tris_local[i] = local_unordered[bvh.order[i]]; }
 
     // LUT pool, CMF, table (repacked to float4 cells), textures (RGBA8)
     std::vector<float> lut_pool;
@@ -532,6 +569,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     if ((rc = upload(this, tris, &dev.tris, err))) return rc;
     if ((rc = upload(this, shade, &dev.shade, err))) return rc;
     if ((rc = upload(this, dinst, &dev.instances, err))) return rc;
+    if ((rc = upload(this, tris_local, &dev.tris_local, err))) return rc;
     {   // per clearcoat material: the coat's directional-albedo table (mi355pt_params.albedo_lut); the device copy of the material names its offset
         std::vector<float> cc_tab;
         std::vector<DevMaterial> mats = materials;
