@@ -134,49 +134,50 @@ def test_image_parity_scene3_mis_sobol(scenes3, product, oracle, pkg):
     assert (np.abs(qg.astype(int) - qc.astype(int)) <= 1).mean() >= 0.97
 
 
-# limits: (rmse of the tone-mapped frames, pixels off by more than 0.01) — default (5e-4, 6); measured values in tools/frame_table.py's
-# output (profiles/r02_frame_table.jsonl): 1e-7 .. 9e-5 and 0 pixels for every pair on the default bar
-FRAME_LIMITS = {
-    7: (2e-3, 24),      # rough gold: grazing microfacet samples amplify last-bit differences of libm (7e-4 / 8 measured)
-    11: (8e-3, 120),    # rough SF11 glass, NEE (3.5e-3 / 45 measured); the MIS frame has NaN pixels (see the radiance test) and is not compared
-    12: (8e-3, 80),     # four rough BK7 heroes (3.4e-3 / 25): GGX visible-normal sampling near the rim of the disk, pz = sqrt(1 - px^2 - py^2),
-    27: (0.03, 150),    # cancels catastrophically, so a 1-ulp sin/cos difference between device and host libm moves the sampled normal
-}
-# share of 30 000 samples whose spectral radiance agrees with the oracle's to 1e-3 (test_other_scenes_radiance_parity): 0.999 unless the scene
-# belongs to one of the two root-caused classes; the values are the measured rates (profiles/r03_per_sample_rates.jsonl) less a margin
-PER_SAMPLE_MIN = {9: 0.996, 13: 0.998,              # solid constant-eta plastic, the reference's own roulette gate: measured 0.9974 / 0.9991
-                  11: 0.993, 12: 0.997, 27: 0.997}     # rough refraction (GGX normal near the rim of the disk): 0.9952 / 0.9989 / 0.9986
-# (every other scene / strategy pair measures 0.9995 ... 1.0000; round 2's bar was 0.98 for all of them)
-KNIFE_EDGE_SCENES = (9, 13, 19)   # solid constant-eta plastic: compared with the Russian-roulette gate relaxed on both sides (next test)
+# Frame bar of the sample-for-sample test: (rmse of the tone-mapped frames, pixels off by more than 0.01).  Round 3 made the shading point
+# the reference's bit for bit (winner_hit / load_surface / shading_frames_numeric / ggx_D / pt_libm.hpp), so there are no per-scene limits and no
+# relaxed roulette gate any more: measured 4e-8 ... 9e-5 and 0 pixels for 49 of the 50 pairs (profiles/r03_frame_table.jsonl; round 2 needed up
+# to 0.03 / 150 pixels on the rough-refraction scenes and rr_gate_slack on the solid-plastic ones).  What is left are single samples — 1 to 4 of
+# the 196 608 of a frame, e.g. scene 4 / mis: one, 3.1e-4 / 1 pixel — whose light connection is occluded on one side only: the any-hit
+# traversal answers on render-space triangles where the reference tests each mesh in its local space, and a grazing shadow ray can graze
+# differently (tests/test_parity_gpu.py::test_secondary_ray_hit_parity has such a ray).  The bar leaves room for two such pixels.
+FRAME_BAR = (5e-4, 2)
+# share of 30 000 samples whose spectral radiance agrees with the oracle's to 1e-3 (test_other_scenes_radiance_parity): measured >= 0.99993
+# for every scene / strategy pair (profiles/r03_per_sample_rates.jsonl; round 2's bar was 0.98, round 3's first 0.993 ... 0.999)
+PER_SAMPLE_MIN = 0.9995
 
 
 @pytest.mark.parametrize("scene_id,strategy", [(0, "mis"), (0, "nee"), (1, "nee"), (2, "mis"), (3, "mis"), (3, "nee"), (3, "pt"), (4, "mis"), (5, "pt"),
-                                               (5, "nee"), (6, "mis"), (7, "mis"), (7, "nee"), (8, "mis"), (9, "mis"), (10, "mis"), (11, "nee"),
+                                               (5, "nee"), (6, "mis"), (7, "mis"), (7, "nee"), (8, "mis"), (9, "mis"), (10, "mis"), (11, "nee"), (11, "mis"),
                                                (12, "mis"), (13, "mis"), (14, "nee"), (15, "mis"), (16, "mis"), (17, "nee"), (17, "mis"), (18, "nee"),
                                                (19, "mis"), (19, "pt"), (19, "nee"), (20, "mis"), (20, "pt"), (21, "mis"), (21, "nee"), (22, "mis"),
                                                (22, "nee"), (27, "mis"), (27, "nee"), (27, "pt"),
                                                (29, "pt"), (29, "nee"), (29, "mis"), (30, "pt"), (30, "nee"), (30, "mis"),
                                                (31, "pt"), (31, "nee"), (31, "mis"), (32, "nee"), (32, "mis")])
 def test_frames_match_the_oracle_sample_for_sample(product, oracle, pkg, scene_id, strategy):
-    """Every scene id of the radiance test, through the scene's own kernel specialisation (= what bench.py runs for it).  Outside rough
-    refraction nothing amplifies a last-bit difference, so GPU and oracle must trace the SAME paths for all but a handful of samples:
-    at 64 spp the tone-mapped frames agree to 5e-4 RMSE with at most 0.2 % of the pixels off by more than 0.01.
-    (The per-sample test allows 1 % of diverging samples; a systematic fault inside that allowance — e.g. a throughput that rounds
-    differently for albedo 1 and so changes the Russian-roulette gate `p >= 1`, which shifts every later Sobol dimension — shows up
-    here as tens of wrong pixels.)  Scenes with a solid constant-eta plastic hero sit on exactly that gate BY THEIR PHYSICS (see
-    test_solid_plastic_flips_are_the_roulette_gate): they are compared with the gate relaxed by 1e-5 on both sides."""
+    """Every scene id of the radiance test, through the scene's own kernel specialisation (= what bench.py runs for it): GPU and oracle
+    trace the SAME paths, with the reference's own Russian-roulette gate, in every scene — rough refraction (scenes 11, 12, 27: round 2
+    compared them on widened limits and not at all under MIS), near-mirror rough metal (7) and the solid constant-eta plastic heroes (9, 13,
+    19: round 2 compared them with the gate relaxed on both sides) included.  At 64 spp the tone-mapped frames agree to 5e-4 RMSE with at
+    most two pixels off by more than 0.01 (FRAME_BAR above: what is left, and why).  What it took is in DESIGN.md 2.1: the shading point rebuilt the reference's way (local-space
+    intersection, numeric matrix inverses), the reference's own ill-conditioned GGX expressions, the host libm's sin / cos."""
     pair = {}
     for name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()
         pair[name] = (sc, pkg.scenes.load_scene(sc, scene_id, 64, 48, tex_size=128))
     oracle.set_faithful(pair["cpu"][0], False)
-    prm = pkg.make_params(64, strategy, "sobol", rr_gate_slack=1e-5 if scene_id in KNIFE_EDGE_SCENES else 0.0)
+    prm = pkg.make_params(64, strategy, "sobol")
     g = product.render(pair["gpu"][0], pair["gpu"][1], prm)
     c = oracle.render(pair["cpu"][0], pair["cpu"][1], prm)
-    rmse = float(np.sqrt(np.mean((g - c) ** 2)))
-    off = int((np.abs(g - c).max(axis=2) > 0.01).sum())
-    lim_rmse, lim_off = FRAME_LIMITS.get(scene_id, (5e-4, 6))
-    assert rmse <= lim_rmse and off <= lim_off, (rmse, off)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(np.isnan(g), np.isnan(c))          # (the reference accumulates NaN samples, sensor.rs:42: the same pixels on both sides)
+        d = np.nan_to_num(g - c)
+    rmse = float(np.sqrt(np.mean(d ** 2)))
+    off = int((np.abs(d).max(axis=2) > 0.01).sum())
+    if os.environ.get("MI355PT_FRAME_LOG"):
+        with open(os.environ["MI355PT_FRAME_LOG"], "a") as f:
+            f.write(f'{{"scene": {scene_id}, "strategy": "{strategy}", "rmse": {rmse:.3e}, "off": {off}, "nan_px": {int(np.isnan(g).any(axis=2).sum())}}}\n')
+    assert rmse <= FRAME_BAR[0] and off <= FRAME_BAR[1], (rmse, off)
 
 
 @pytest.mark.parametrize("scene_id,strategy", [(17, "nee"), (17, "mis"), (16, "mis"), (18, "nee"), (19, "mis")])
@@ -191,33 +192,29 @@ def test_albedo_lut_frames_match_the_oracle(product, oracle, pkg, scene_id, stra
         pair[name] = (sc, pkg.scenes.load_scene(sc, scene_id, 64, 48, tex_size=128))
     oracle.set_faithful(pair["cpu"][0], False)
     oracle.set_clearcoat_mode(pair["cpu"][0], "lut", product)
-    prm = pkg.make_params(64, strategy, "sobol", albedo_lut=1, rr_gate_slack=1e-5 if scene_id in KNIFE_EDGE_SCENES else 0.0)
+    prm = pkg.make_params(64, strategy, "sobol", albedo_lut=1)
     g = product.render(pair["gpu"][0], pair["gpu"][1], prm)
     c = oracle.render(pair["cpu"][0], pair["cpu"][1], prm)
     rmse = float(np.sqrt(np.mean((g - c) ** 2)))
     off = int((np.abs(g - c).max(axis=2) > 0.01).sum())
-    assert rmse <= 5e-4 and off <= 6, (rmse, off)
+    assert rmse <= FRAME_BAR[0] and off <= FRAME_BAR[1], (rmse, off)
     # and the option is an option: the default (64-sample estimate) gives another, equally noisy, frame of the same scene
     d = product.render(pair["gpu"][0], pair["gpu"][1], pkg.make_params(64, strategy, "sobol"))
     assert not np.array_equal(d, g) and abs(float(d.mean()) - float(g.mean())) <= 0.01 * float(g.mean())
 
 
 @pytest.mark.parametrize("scene_id", [9, 13])
-def test_solid_plastic_flips_are_the_roulette_gate(product, oracle, pkg, scene_id):
-    """Root cause of the round-1 'open divergence' on the solid plastic heroes (scene_9.rs, scene_13.rs): a specular REFLECTION off a
+def test_solid_plastic_paths_follow_the_reference_gate(product, oracle, pkg, scene_id):
+    """Rounds 1-2's 'open divergence' on the solid plastic heroes (scene_9.rs, scene_13.rs), closed in round 3.  A specular REFLECTION off a
     constant-eta dielectric returns f = F and pdf = F / (F + (1 - F)) (dielectric.rs:380-466), so the throughput becomes
-    T * (F * (1 / pdf)) = 1 or 1 - 1 ulp depending on the last bit of F — and apply_russian_roulette (base_renderer.rs:76-92) draws
-    its random number only if max(T) < 1.  cos(theta) differs between product and reference in the last ulp for a share of the vertices,
-    F with it, the gate falls the other way and every later Sobol dimension of that sample shifts (a different but equally valid path).
-    Where the ulp comes from was measured in round 3 (tools/frame_inverse_probe.py, profiles/r03_frame_inverse_probe.jsonl): the product
-    intersects triangles pre-translated to render space where the reference moves each ray into the primitive's local space, and it
-    transposes the shading frame where the reference inverts a Mat4 numerically (pt_path.hpp PT_FRAME_INVERSE builds glam's inverse: by
-    itself 0.286 % -> 0.263 % on scene 9, together with a render-space oracle 0.053 %) — two roundings that compound, and a third source
-    not yet found.  Proof by intervention that the GATE is where the paths part:
-    with the gate relaxed to max(T) >= 1 - 1e-5 on BOTH sides (mi355pt_params.rr_gate_slack) the two implementations trace the same
-    paths again; with the reference's gate the share of flipped samples is what tools/divergence_probe.py measured (0.29 % / 0.09 %,
-    first differing depth spread evenly over the path: profiles/r02_divergence_scene{9,13}.json).  Dispersive glass (scene 8: F differs
-    per wavelength, max(T) > 1) and the thin film (scene 10: pdf is the cumulative reflectance, T < 1) are nowhere near the gate."""
+    T * (F * (1 / pdf)) = 1 or 1 - 1 ulp depending on the last bit of F — and apply_russian_roulette (base_renderer.rs:76-92) draws its
+    random number only if max(T) < 1: an implementation whose cos(theta) differs in the last ulp takes the other branch and every later
+    Sobol dimension of the sample shifts.  Round 2 proved the gate was where the paths parted (relaxing it to max(T) >= 1 - 1e-5 on both
+    sides brought them together: 0.29 % / 0.09 % of the samples -> 1e-5) and compared these scenes only that way.  Round 3 removed the ulp
+    instead: the product now intersects the triangle it found in the mesh's local space and carries the hit back through local_to_render
+    like primitive/impls/triangle_mesh.rs:89-119, inverts the shading frame numerically like math/src/transform.rs:186-203, and computes
+    sin / cos like the host's libm (pt_libm.hpp).  With the REFERENCE'S OWN gate (rr_gate_slack = 0, the only value a caller can set
+    without mi355pt_debug_unlock) at most 1e-4 of the samples differ now; measured 0 of 196 608 on both scenes."""
     pair = {}
     for name, be in (("gpu", product), ("cpu", oracle)):
         sc = be.new_scene()
@@ -225,16 +222,12 @@ def test_solid_plastic_flips_are_the_roulette_gate(product, oracle, pkg, scene_i
     oracle.set_faithful(pair["cpu"][0], False)
     ys, xs, ss = np.meshgrid(np.arange(48), np.arange(64), np.arange(64), indexing="ij")
     xys = np.stack([xs.ravel(), ys.ravel(), ss.ravel()], 1).astype(np.uint32)
-    share = {}
-    for slack in (0.0, 1e-5):
-        prm = pkg.make_params(64, "mis", "sobol", rr_gate_slack=slack)
-        Lg, lg, pg = pair["gpu"][0].probe_radiance(pair["gpu"][1], prm, xys)
-        Lc, lc, pc = pair["cpu"][0].probe_radiance(pair["cpu"][1], prm, xys)
-        assert np.array_equal(lg, lc) and np.array_equal(pg, pc)
-        share[slack] = float((~np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)).mean())
-    assert share[1e-5] <= 1e-4, share            # measured 1e-5 (2 of 196 608 samples) / 0
-    assert share[0.0] <= 6e-3, share             # measured 2.9e-3 / 8.9e-4: the reference's own gate, flipped by last-ulp differences
-    assert share[0.0] >= 10 * share[1e-5]
+    prm = pkg.make_params(64, "mis", "sobol")
+    Lg, lg, pg = pair["gpu"][0].probe_radiance(pair["gpu"][1], prm, xys)
+    Lc, lc, pc = pair["cpu"][0].probe_radiance(pair["cpu"][1], prm, xys)
+    assert np.array_equal(lg, lc) and np.array_equal(pg, pc)
+    share = float((~np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)).mean())
+    assert share <= 1e-4, share
 
 
 def test_config1_pt_random(scenes3, product, oracle, pkg):
@@ -315,34 +308,29 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
     assert np.array_equal(lg, lc)
     same_term = np.all(pg == pc, axis=1)
     assert same_term.mean() >= 0.995
-    close = np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)
+    with np.errstate(invalid="ignore"):
+        close = np.all((np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4) | (np.isnan(Lg) & np.isnan(Lc)), axis=1)   # (NaN samples: scene 11 under MIS, see below)
     if os.environ.get("MI355PT_PARITY_LOG"):                              # measurement run behind PER_SAMPLE_MIN (below)
         with open(os.environ["MI355PT_PARITY_LOG"], "a") as f:
             f.write(f'{{"scene": {scene_id}, "strategy": "{strategy}", "close": {close.mean():.6f}, "same_term": {same_term.mean():.6f}}}\n')
-    assert close.mean() >= PER_SAMPLE_MIN.get(scene_id, 0.999), close.mean()
+    assert close.mean() >= PER_SAMPLE_MIN, close.mean()
     # The reference accumulates NaN samples without complaint (sensor.rs:42 only logs).  Rough SF11 glass under MIS makes
     # some: below 370 nm the eta LUT is 0 -> eta' = 1 (dielectric.rs:144-148), the "refracted" ray is -wo, and whenever
     # dot(wi,wm) + dot(wo,wm) rounds to exactly 0 the sample has f = 0 (spectrum / 0 -> 0), pdf = inf and the MIS weight
-    # inf/(inf+0) = NaN.  Whether the sum rounds to 0 depends on the last ulp of sin/cos in the GGX normal sample, so
-    # the two sides agree on the mechanism and the rate, not on every sample: both must be rare, of similar count, and
-    # only ever on hero wavelengths below 370 nm.
+    # inf/(inf+0) = NaN.  Whether the sum rounds to 0 depends on the last ulp of the sampled normal: with the shading point rebuilt the
+    # reference's way (round 3) both sides make the SAME NaN samples, all of them on hero wavelengths below 370 nm.
     nan_g, nan_c = np.isnan(Lg).any(axis=1), np.isnan(Lc).any(axis=1)
     bad = nan_g | nan_c
     assert bad.mean() <= 5e-3, bad.mean()
-    if nan_c.sum() >= 20:
-        assert 0.5 * nan_c.sum() <= nan_g.sum() <= 2.0 * nan_c.sum(), (nan_g.sum(), nan_c.sum())
+    assert np.count_nonzero(nan_g != nan_c) <= 1, (int(nan_g.sum()), int(nan_c.sum()))
     assert np.all(lg[nan_g, 0] < 370.0) and np.all(lc[nan_c, 0] < 370.0)
-    assert abs(Lg[~bad, 0].mean() - Lc[~bad, 0].mean()) <= 0.02 * Lc[~bad, 0].mean()
+    assert abs(Lg[~bad, 0].mean() - Lc[~bad, 0].mean()) <= 2e-3 * Lc[~bad, 0].mean()
     # (the probe is the per-sample log of the scene's own kernel specialisation, written by the production launch)
     # compare a small image too (reference metric, regression_test.rs:6-40)
-    # (solid constant-eta plastic heroes: Russian-roulette gate relaxed on both sides, see test_solid_plastic_flips_are_the_roulette_gate)
-    prm8 = pkg.make_params(8, strategy, "sobol", rr_gate_slack=1e-5 if scene_id in KNIFE_EDGE_SCENES else 0.0)
+    prm8 = pkg.make_params(8, strategy, "sobol")
     qg = product.quantize_u8(product.render(pair["gpu"][0], pair["gpu"][1], prm8))
     qc = oracle.quantize_u8(oracle.render(pair["cpu"][0], pair["cpu"][1], prm8))
-    # 8-spp frames of ROUGH refraction: GGX normal sampling near the rim of the disk amplifies 1-ulp libm differences (FRAME_LIMITS), and a
-    # NaN sample blacks out its pixel (`as u8`, scene 11); everything else is on the 0.01 bar
-    tol = {11: 0.03, 12: 0.02, 27: 0.02}.get(scene_id, 0.01)
-    assert linear_rmse_u8(qg, qc) <= tol
+    assert linear_rmse_u8(qg, qc) <= 2e-3      # (the reference's own pass bar is 0.05; round 2 needed 0.01 ... 0.03 here)
 
 
 @pytest.mark.parametrize("strategy", ["pt", "nee", "mis"])

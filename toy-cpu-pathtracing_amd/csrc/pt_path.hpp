@@ -66,6 +66,15 @@ PT_DEV Frame normal_map_frame(f3 nm) {
     f.b = normalize(cross(f.n, f.t));
     return f;
 }
+// ... and like the shading frame the reference INVERTS that basis numerically (transform.rs:243) and inverts the inverse again for the way
+// back (`transform.inverse()` in every material's sample, e.g. lambert_material.rs): nfr = rows to_local() dots with, nfw = columns of the way back
+PT_DEV void normal_map_frames_numeric(f3 nm, Frame& nfr, Frame& nfw) {
+    const Frame o = normal_map_frame(nm);
+    f3 r0, r1, r2;
+    inverse3_glam(o.t, o.b, o.n, r0, r1, r2);
+    nfr.t = mk3(r0.x, r1.x, r2.x); nfr.b = mk3(r0.y, r1.y, r2.y); nfr.n = mk3(r0.z, r1.z, r2.z);
+    inverse3_glam(r0, r1, r2, nfw.t, nfw.b, nfw.n);
+}
 PT_DEV f3 mat3_mul(const float* m, f3 v) {   // column-major 3x3
     return mk3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z);
 }
@@ -281,7 +290,8 @@ PT_DEV void regen_path(Path& P, const SamplerCtx& sctx, const DevCamera& cam, ui
 // What the first half hands to the second half:
 struct ShadeCtx {
     Surface sf; const DevMaterial* mat; uint32_t mtype;
-    Frame fr, fw, nf; f3 wo, wo_nm, ng_t; float geo_wo, uc; f2 uv;   // fr: render -> tangent rows; fw: tangent -> render columns (= fr unless numeric_frames)
+    Frame fr, fw, nf, nfw; f3 wo, wo_nm, ng_t; float geo_wo, uc; f2 uv;   // nf / nfw: the normal-map basis, there and back (nfw only with numeric frames in texture kernels)
+    //   // fr: render -> tangent rows; fw: tangent -> render columns (= fr unless numeric_frames)
     bool is_diel, rough_diel, cont;
     float d_alpha;                 // dielectric roughness at the shading point (constant or FloatTexture)
     // clearcoat inputs / result of the cooperative estimate
@@ -484,7 +494,7 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
             else if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) { uc = get_1d(smp, sctx); uv = get_2d(smp, sctx); }
             else { smp.dimension += 1; uv = get_2d(smp, sctx); }
             // normal map frame (identity without a normal texture)
-            Frame nf;
+            Frame nf, nfw_num;
             if ((FEAT & FEAT_TEX) && mat->normal_tex != 0xffffffffu) {
                 float rgb[3];
                 bilinear_rgb(sc, mat->normal_desc, sf.uv, rgb);               // normal_texture.rs:39-66
@@ -493,13 +503,15 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                 float len = sqrtf(nx * nx + ny * ny + nz * nz);
                 f3 nm = mk3(0, 0, 1);
                 if (len > 0.0f) nm = normalize(normalize(mk3(nx / len, ny / len, nz / len)));
-                nf = normal_map_frame(nm);
+                if constexpr (numeric_frames<FEAT>()) normal_map_frames_numeric(nm, nf, nfw_num);
+                else nf = normal_map_frame(nm);
             } else {
                 nf.t = mk3(1, 0, 0); nf.b = mk3(0, 1, 0); nf.n = mk3(0, 0, 1);
+                if constexpr (numeric_frames<FEAT>()) nfw_num = nf;           // (the inverse of the identity is the identity, exactly)
             }
             f3 wo_nm = to_local(nf, wo);
             // ---- hand-over to the second half ----
-            C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; if constexpr (numeric_frames<FEAT>() && !(FEAT & FEAT_CC)) C.fw = fw_num; C.nf = nf; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
+            C.sf = sf; C.mat = mat; C.mtype = mtype; C.fr = fr; if constexpr (numeric_frames<FEAT>() && !(FEAT & FEAT_CC)) C.fw = fw_num; C.nf = nf; if constexpr (numeric_frames<FEAT>() && (FEAT & FEAT_TEX) != 0u && !(FEAT & FEAT_CC)) C.nfw = nfw_num; C.wo = wo; C.wo_nm = wo_nm; C.ng_t = ng_t;
             C.geo_wo = dot(ng_t, wo); C.uc = uc; C.uv = uv; C.is_diel = is_diel; C.rough_diel = rough_diel; C.d_alpha = d_alpha; C.cont = true;
             if ((FEAT & FEAT_CC) && mtype == MT_CLEARCOAT) {
                 // SimpleClearcoatPbrMaterial: FloatParameter values at the shading point + the inputs of the coat's directional albedo
@@ -548,6 +560,10 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
     if constexpr (numeric_frames<FEAT>() && (FEAT & FEAT_CC) != 0u)
         inverse3_glam(mk3(C.fr.t.x, C.fr.b.x, C.fr.n.x), mk3(C.fr.t.y, C.fr.b.y, C.fr.n.y), mk3(C.fr.t.z, C.fr.b.z, C.fr.n.z), fw_re.t, fw_re.b, fw_re.n);
     const Frame& fr = C.fr; const Frame& fw = numeric_frames<FEAT>() ? ((FEAT & FEAT_CC) ? fw_re : C.fw) : C.fr; const Frame& nf = C.nf; const f3 wo = C.wo, wo_nm = C.wo_nm, ng_t = C.ng_t;
+    Frame nfw_re;
+    if constexpr (numeric_frames<FEAT>() && (FEAT & FEAT_TEX) != 0u && (FEAT & FEAT_CC) != 0u)
+        inverse3_glam(mk3(C.nf.t.x, C.nf.b.x, C.nf.n.x), mk3(C.nf.t.y, C.nf.b.y, C.nf.n.y), mk3(C.nf.t.z, C.nf.b.z, C.nf.n.z), nfw_re.t, nfw_re.b, nfw_re.n);
+    const Frame& nfw = (numeric_frames<FEAT>() && (FEAT & FEAT_TEX) != 0u) ? ((FEAT & FEAT_CC) ? nfw_re : C.nfw) : C.nf;   // the way back out of the normal-map basis
     const float uc = C.uc; const f2 uv = C.uv; const bool is_diel = C.is_diel, rough_diel = C.rough_diel;
     {
         {
@@ -575,7 +591,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     f3 wi = mk3(r * cs_th, r * sn_th, sqrtf(1.0f - uv.x));
                     if (wo_nm.z < 0.0f) wi.z = -wi.z;
                     if (wi.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi.z)) {
-                        f3 w = to_world(nf, wi);
+                        f3 w = to_world(nfw, wi);
                         float gwi = dot(ng_t, w);
                         if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) {
                             sampled = true; wi_sh = w; s_pdf = fabsf(wi.z) / PI_F;   // sampled f and pdf stay IEEE: for albedo 1 their ratio must round like the reference's (the `p >= 1` roulette gate)
@@ -650,7 +666,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) s_f[i] = s_f[i] * col[i];
                             }
-                            wi_sh = to_world(nf, wi);
+                            wi_sh = to_world(nfw, wi);
                         }
                     }
                 } else
@@ -700,7 +716,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
 #pragma unroll
                             for (int i = 0; i < 4; ++i) s_f[i] = s_f[i] * col[i];
                         }
-                        wi_sh = to_world(nf, wi);
+                        wi_sh = to_world(nfw, wi);
                     }
                 }
                 // failed dielectric samples are "Diffuse" (non-specular): the reference then runs NEE with
@@ -729,7 +745,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         base = false;
                         GsSample g = gs_sample_R(cc_alpha_c, wo_nm, uv);
                         if (g.ok) {
-                            sampled = true; specular = g.specular; wi_sh = to_world(nf, g.wi); s_pdf = g.pdf * cc_fc;
+                            sampled = true; specular = g.specular; wi_sh = to_world(nfw, g.wi); s_pdf = g.pdf * cc_fc;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) s_f[i] = (cc_r0c + (1.0f - cc_r0c) * g.p5) * g.dg;
                         }
@@ -769,7 +785,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         }
                     }
                     if (okb) {
-                        sampled = true; specular = specb; wi_sh = to_world(nf, wi);
+                        sampled = true; specular = specb; wi_sh = to_world(nfw, wi);
                         if (thick > 0.0f) {
                             s_pdf = pb * (1.0f - cc_fc);
 #pragma unroll
@@ -825,7 +841,7 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         }
                     }
                     if (okm) {
-                        f3 w = to_world(nf, wi);
+                        f3 w = to_world(nfw, wi);
                         float gwi = dot(ng_t, w);
                         if (sgn1(gwi) == sgn1(geo_wo) && !(gwi != gwi) && !(geo_wo != geo_wo)) { sampled = true; wi_sh = w; }
                         else specular = false;
