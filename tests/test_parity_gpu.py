@@ -57,8 +57,8 @@ def test_closest_hit_parity(scenes3):
     same = (ig == ic) & (trg == trc)
     assert same.mean() >= 0.9999, same.mean()
     rel = np.abs(tg[same] - tc[same]) / np.maximum(np.abs(tc[same]), 1e-6)
-    assert rel.max() <= 2e-6, rel.max()
-    assert np.abs(ng[same] - nc[same]).max() <= 1e-5
+    assert rel.max() <= 2.5e-7, rel.max()       # (round 3: the probe reports the reference's local-space t of the triangle found: the same float, up to the rare render-space fallback)
+    assert np.abs(ng[same] - nc[same]).max() <= 2.5e-7
 
 
 def test_secondary_ray_hit_parity(scenes3):
@@ -119,8 +119,8 @@ def test_per_sample_radiance_parity(scenes3, product, pkg, strategy):
     assert np.array_equal(lg, lc)              # wavelengths come straight from Sobol bits
     assert np.array_equal(pg, pc)
     close = np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)
-    assert close.mean() >= 0.99, close.mean()
-    assert abs(Lg.mean() - Lc.mean()) <= 0.01 * Lc.mean()
+    assert close.mean() >= 0.9995, close.mean()
+    assert abs(Lg.mean() - Lc.mean()) <= 1e-3 * Lc.mean()
 
 
 def test_image_parity_scene3_mis_sobol(scenes3, product, oracle, pkg):
@@ -130,8 +130,8 @@ def test_image_parity_scene3_mis_sobol(scenes3, product, oracle, pkg):
     img_g = product.render(scenes3["gpu"][0], scenes3["gpu"][1], prm)
     img_c = oracle.render(scenes3["cpu"][0], scenes3["cpu"][1], prm)
     qg, qc = product.quantize_u8(img_g), oracle.quantize_u8(img_c)
-    assert linear_rmse_u8(qg, qc) <= 0.004
-    assert (np.abs(qg.astype(int) - qc.astype(int)) <= 1).mean() >= 0.97
+    assert linear_rmse_u8(qg, qc) <= 0.001
+    assert (np.abs(qg.astype(int) - qc.astype(int)) <= 1).mean() >= 0.999
 
 
 # Frame bar of the sample-for-sample test: (rmse of the tone-mapped frames, pixels off by more than 0.01).  Round 3 made the shading point
@@ -507,7 +507,7 @@ def test_launch_shape_does_not_change_the_frame(product, oracle, pkg, scene_id, 
         img_g = product.render(sc, cam, prm)
         # (solid glass: a refracted path that flips at an edge or at a Russian-roulette threshold moves its pixel by a lot; the
         # reference's own regression thresholds are 0.05-0.085, regression_test.rs:109-659)
-        assert linear_rmse_u8(product.quantize_u8(img_g), oracle.quantize_u8(img_o)) <= (0.02 if scene_id == 8 else 0.01)
+        assert linear_rmse_u8(product.quantize_u8(img_g), oracle.quantize_u8(img_o)) <= 2e-3
 
 
 # (name, scene, W, H, spp, strategy, shard_count): every BASELINE.json config at its TRUE size; the shard holds 4-9 tiles spread over the frame
@@ -563,7 +563,7 @@ def test_baseline_configs_at_true_size_match_the_oracle(product, oracle, pkg, na
     Lg, lg, pg = L[k, pix, s], lam[k, pix, s], pdf[k, pix, s]
     assert np.array_equal(lg, lc) and np.array_equal(pg, pc)               # wavelengths and termination: straight from the Sobol bits
     close = np.all(np.abs(Lg - Lc) <= 1e-3 * np.abs(Lc) + 1e-4, axis=1)
-    assert close.mean() >= 0.999, close.mean()
+    assert close.mean() >= 0.9995, close.mean()
 
 
 @pytest.mark.parametrize("device_ids", [[0], [0, 0, 0], "all", "all_reversed"])
@@ -627,7 +627,7 @@ def test_dielectric_roughness_map_is_used(product, oracle, pkg):
     d_gpu = linear_rmse_u8(frames["gpu", 27], frames["gpu", 28])
     d_cpu = linear_rmse_u8(frames["cpu", 27], frames["cpu", 28])
     assert d_gpu > 0.01 and abs(d_gpu - d_cpu) <= 0.2 * d_cpu, (d_gpu, d_cpu)
-    assert linear_rmse_u8(frames["gpu", 27], frames["cpu", 27]) <= 0.02
+    assert linear_rmse_u8(frames["gpu", 27], frames["cpu", 27]) <= 2e-3
 
 
 def test_cpp_host_cli_matches_python_binding(product, pkg, tmp_path):
