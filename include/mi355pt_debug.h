@@ -38,6 +38,10 @@ int mi355pt_probe_bvh_collapse_nodes(const void* bvh2_nodes, uint32_t n_nodes, i
  * pattern string `pattern` of '1' (get_1d) and '2' (get_2d) characters.  z_sobol_sampler.rs:198-230 */
 int mi355pt_probe_sobol(uint32_t width, uint32_t height, uint32_t spp, uint32_t seed, const uint32_t* xys /* n*3 */,
                         uint32_t n, const char* pattern, uint32_t* out_bits /* n * n_values(pattern) */);
+/* sin / cos as the render kernels compute them (csrc/pt_libm.hpp: the host libm's algorithm restated; the reference calls f32::sin_cos,
+ * e.g. scene/src/material/bsdf/dielectric.rs:77-112 via common.rs) for the n floats with bit patterns first_bits + i * stride, compared on
+ * the host with sinf / cosf of THIS machine's libm: out_counts[3] = {compared, sin results that differ in any bit, cos results}. */
+int mi355pt_probe_sincos(uint32_t first_bits, uint32_t stride, uint32_t n, uint64_t* out_counts /* 3 */);
 /* Scene::intersect for n rays (render space).  out_t < 0 means miss.  scene.rs:80-90 */
 int mi355pt_probe_intersect(const mi355pt_scene* s, const float* origins, const float* dirs, uint32_t n, float* out_t,
                             uint32_t* out_instance, uint32_t* out_triangle, float* out_normal /* n*3 geometric, NULL ok */);

@@ -234,3 +234,20 @@ def test_baked_cmf_and_d65_match_the_references_second_copy():
     for c, row in enumerate(("cie_x", "cie_y", "cie_z")):
         assert np.array_equal(cmf[:, c], lut[names.index(row)])
     assert not cmf[:, 3].any()
+
+
+def test_device_sincos_restatement_equals_the_host_libm(tmp_path):
+    """csrc/pt_libm.hpp (glibc's sinf / cosf restated in double for the device: the reference's f32::sin_cos is the host libm) compiled for
+    the HOST from the same header and compared with this machine's libm float by float: every 61st float of [-120, 120] here (36.8 M values
+    x 2 functions, ~1 s; stride 1 = all 2 246 049 792 of them was run when the header was written: 0 mismatches on glibc 2.35), plus that
+    libm's sincosf returns the same two floats as sinf and cosf (Rust's sin_cos may lower to either).  No GPU involved; the GPU side of the
+    same statement is tests/test_parity_gpu.py::test_device_sincos_equals_the_host_libm."""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "libm_check")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-mfma", "-o", exe, os.path.join(root, "tools", "libm_check.cpp")], check=True)
+    r = subprocess.run([exe, "61"], capture_output=True, text=True)
+    out = json.loads(r.stdout)
+    assert r.returncode == 0, out
+    assert out["compared"] >= 36_000_000 and out["sin_mismatches"] == 0 and out["cos_mismatches"] == 0
+    assert out["libm_sincosf_differs_from_sinf_cosf"] == 0 and out["out_of_range_refused"] is True

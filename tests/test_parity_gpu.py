@@ -726,3 +726,15 @@ def test_rr_gate_slack_is_refused_unless_unlocked(product, pkg):
     finally:
         product.debug_unlock(was)
     product.render(sc, cam, prm)
+
+
+def test_device_sincos_equals_the_host_libm(product):
+    """The reference's sin / cos are the host libm's (Rust f32::sin_cos -> sinf / cosf; GGX normal sampling, cosine hemisphere, conductor
+    Fresnel, environment map).  csrc/pt_libm.hpp restates glibc's algorithm for the device; mi355pt_probe_sincos runs the render kernels'
+    function (ref_sincosf) on the GPU and compares with THIS host's libm bit for bit: all 1 087 M floats of [0, 2 pi) would take a minute of host libm
+    time, so every 64th of them (17 M), every 4 099th float of (-120, 120) and the first 2^20 floats above 0 (subnormals, tiny arguments).
+    Beyond +-120 the kernels fall back to the device libm (no call site produces such angles): a range that must merely stay finite."""
+    two_pi_bits = 0x40C90FDB
+    for first, stride, n in ((0, 64, two_pi_bits // 64), (0, 4099, 0x42F00000 // 4099), (0x80000000, 4099, 0x42F00000 // 4099), (0, 1, 1 << 20)):
+        compared, bad_s, bad_c = product.probe_sincos(first, stride, n)
+        assert compared == n and bad_s == 0 and bad_c == 0, (hex(first), stride, n, bad_s, bad_c)

@@ -25,6 +25,7 @@ hipError_t launch_film_unpack(float*, uint32_t, uint32_t, uint32_t, uint32_t, ui
 hipError_t launch_probe_sobol(uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t*, hipStream_t);
 hipError_t launch_probe_intersect(const DevScene&, const float*, const float*, uint32_t, float*, uint32_t*, uint32_t*, float*, hipStream_t);
 hipError_t launch_probe_occluded(const DevScene&, const float*, const float*, const float*, uint32_t, uint8_t*, hipStream_t);
+hipError_t launch_probe_sincos(uint32_t, uint32_t, uint32_t, float*, float*, hipStream_t);
 uint64_t host_murmur_dim_seed(uint32_t dimension, uint32_t seed);
 int query_resident_waves(bool stats, uint32_t feat, uint32_t sampler, uint32_t strategy);
 }  // namespace pt
@@ -881,6 +882,30 @@ int mi355pt_probe_occluded(const mi355pt_scene* s, const float* o, const float* 
     HIP_TRY(hipMemcpy(d_t.p, tmax, sizeof(float) * n, hipMemcpyHostToDevice));
     HIP_TRY(launch_probe_occluded(s->impl.dev, d_o.p, d_d.p, d_t.p, n, d_out.p, nullptr));
     HIP_TRY(hipMemcpy(out, d_out.p, n, hipMemcpyDeviceToHost));
+    return MI355PT_OK;
+}
+
+int mi355pt_probe_sincos(uint32_t first_bits, uint32_t stride, uint32_t n, uint64_t* out_counts) {
+    if (!out_counts || stride == 0) return fail(MI355PT_E_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI355PT_E_NO_DEVICE, "no HIP device");
+    out_counts[0] = out_counts[1] = out_counts[2] = 0;
+    if (n == 0) return MI355PT_OK;
+    if ((uint64_t)first_bits + (uint64_t)(n - 1) * stride > 0xffffffffull) return fail(MI355PT_E_INVALID, "bit patterns wrap");
+    DevBuf<float> d_s, d_c;
+    HIP_TRY(d_s.alloc(n)); HIP_TRY(d_c.alloc(n));
+    HIP_TRY(launch_probe_sincos(first_bits, stride, n, d_s.p, d_c.p, nullptr));
+    std::vector<float> hs(n), hc(n);
+    HIP_TRY(hipMemcpy(hs.data(), d_s.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hc.data(), d_c.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t b = first_bits + i * stride;
+        float x; std::memcpy(&x, &b, 4);
+        const float ls = sinf(x), lc = cosf(x);                                   // the libm of this host: what f32::sin / f32::cos call
+        out_counts[0]++;
+        out_counts[1] += std::memcmp(&ls, &hs[i], 4) != 0 && !(std::isnan(ls) && std::isnan(hs[i]));
+        out_counts[2] += std::memcmp(&lc, &hc[i], 4) != 0 && !(std::isnan(lc) && std::isnan(hc[i]));
+    }
     return MI355PT_OK;
 }
 

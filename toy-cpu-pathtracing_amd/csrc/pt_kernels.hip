@@ -95,6 +95,14 @@ __global__ __launch_bounds__(64) void probe_intersect_kernel(DevScene sc, const 
     }
 }
 
+// ref_sincosf (pt_device.hpp -> pt_libm.hpp) for the floats with bit patterns first + i * stride: mi355pt_probe_sincos compares them with the host's libm
+__global__ void probe_sincos_kernel(uint32_t first, uint32_t stride, uint32_t n, float* __restrict__ out_s, float* __restrict__ out_c) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    ref_sincosf(__uint_as_float(first + i * stride), &s, &c);
+    out_s[i] = s; out_c[i] = c;
+}
 __global__ __launch_bounds__(64) void probe_occluded_kernel(DevScene sc, const float* __restrict__ o, const float* __restrict__ d,
                                                             const float* __restrict__ tmax, uint32_t n, uint8_t* __restrict__ out) {
     __shared__ uint32_t s_stack[STACK_DEPTH * 64];
@@ -225,6 +233,10 @@ hipError_t launch_probe_intersect(const DevScene& sc, const float* o, const floa
     }
 #endif
     hipLaunchKernelGGL(probe_intersect_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, sc, o, d, n, t, inst, tri, nrm);
+    return hipGetLastError();
+}
+hipError_t launch_probe_sincos(uint32_t first, uint32_t stride, uint32_t n, float* out_s, float* out_c, hipStream_t stream) {
+    hipLaunchKernelGGL(probe_sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, first, stride, n, out_s, out_c);
     return hipGetLastError();
 }
 hipError_t launch_probe_occluded(const DevScene& sc, const float* o, const float* d, const float* tmax, uint32_t n, uint8_t* out, hipStream_t stream) {

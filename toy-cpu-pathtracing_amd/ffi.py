@@ -120,7 +120,7 @@ def _ptr(a, ty):
 
 
 # every symbol include/mi355pt.h declares (tests/test_abi.py checks the built library exports all of them) ...
-DEBUG_SYMBOLS = ["debug_unlock", "scene_export_bvh", "probe_bvh_collapse", "probe_bvh_collapse_nodes", "probe_sobol", "probe_intersect", "probe_occluded",
+DEBUG_SYMBOLS = ["debug_unlock", "scene_export_bvh", "probe_bvh_collapse", "probe_bvh_collapse_nodes", "probe_sobol", "probe_sincos", "probe_intersect", "probe_occluded",
                  "sample_log_records", "render_sample_log", "probe_radiance"]     # ... and include/mi355pt_debug.h
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
@@ -151,6 +151,8 @@ class Backend:
         f("probe_sobol").argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32)]
         f("probe_intersect").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float),
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        if prefix == "mi355pt_":                                              # (product only: the oracle IS the host libm)
+            f("probe_sincos").argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         f("probe_occluded").argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32,
                                         C.POINTER(C.c_uint8)]
         f("probe_radiance").argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.POINTER(C.c_uint32), C.c_uint32,
@@ -170,6 +172,12 @@ class Backend:
 
     def new_scene(self):
         return SceneHandle(self)
+
+    def probe_sincos(self, first_bits, stride, n):
+        """(compared, sin mismatches, cos mismatches) of the device's sin / cos against this host's libm (include/mi355pt_debug.h)"""
+        out = (C.c_uint64 * 3)()
+        self.check(self.fn("probe_sincos")(first_bits, stride, n, out), "probe_sincos")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def probe_sobol(self, width, height, spp, seed, xys, pattern):
         xys = np.ascontiguousarray(xys, dtype=np.uint32).reshape(-1, 3)
