@@ -52,7 +52,10 @@ def film_digest(t):
     """sha256 of the linear film (bit pattern, row-major H x W x 3 f32) + order-independent moments of it"""
     import hashlib
     a = t.detach().cpu().contiguous().numpy()
-    return hashlib.sha256(a.tobytes()).hexdigest(), float(a.astype("float64").mean()), float(a.astype("float64").max())
+    import numpy as np
+    fin = np.isfinite(a)                                    # (the reference accumulates NaN samples, sensor.rs:42: moments over the finite values, their count beside them)
+    a64 = a.astype("float64")[fin]
+    return hashlib.sha256(a.tobytes()).hexdigest(), float(a64.mean()) if a64.size else 0.0, float(a64.max()) if a64.size else 0.0, int((~fin).sum())
 
 
 def find_profile(name, wl):
@@ -180,19 +183,19 @@ def main():
     film_check = None
     if rank == 0 and frame_per_step and args.steps > 0:
         key = f"scene{args.scene} {W}x{H} {args.strategy}+{args.sampler} {spp_job}spp"
-        sha, mean, mx = film_digest(accum)
+        sha, mean, mx, non_finite = film_digest(accum)
         path = os.path.join(ROOT, "profiles", "film_checksums.json")
         book = json.load(open(path)) if os.path.exists(path) else {}
         if args.write_film_checksum:
-            book[key] = {"library": prod.version(), "sha256": sha, "mean": mean, "max": mx, "n_gpus": world}
+            book[key] = {"library": prod.version(), "sha256": sha, "mean": mean, "max": mx, "non_finite_values": non_finite, "n_gpus": world}
             json.dump(book, open(path, "w"), indent=1, sort_keys=True)
         ref = book.get(key)
-        film_check = {"sha256": sha, "mean": round(mean, 6), "committed": None, "bit_exact": None, "mean_rel_err": None}
+        film_check = {"sha256": sha, "mean": round(mean, 6), "non_finite_values": non_finite, "committed": None, "bit_exact": None, "mean_rel_err": None}
         if ref:
             same_build = ref["library"] == prod.version()
             film_check.update({"committed": ref["sha256"], "committed_library": ref["library"], "bit_exact": (sha == ref["sha256"]) if same_build else None,
                                "mean_rel_err": abs(mean - ref["mean"]) / max(abs(ref["mean"]), 1e-30)})
-            if (same_build and sha != ref["sha256"]) or film_check["mean_rel_err"] > 1e-5:
+            if (same_build and sha != ref["sha256"]) or not (film_check["mean_rel_err"] <= 1e-5) or non_finite != ref.get("non_finite_values", 0):
                 print(json.dumps({"error": "film check failed", "film_check": film_check}), file=sys.stderr, flush=True)
                 raise SystemExit(3)
 

@@ -738,3 +738,28 @@ def test_device_sincos_equals_the_host_libm(product):
     for first, stride, n in ((0, 64, two_pi_bits // 64), (0, 4099, 0x42F00000 // 4099), (0x80000000, 4099, 0x42F00000 // 4099), (0, 1, 1 << 20)):
         compared, bad_s, bad_c = product.probe_sincos(first, stride, n)
         assert compared == n and bad_s == 0 and bad_c == 0, (hex(first), stride, n, bad_s, bad_c)
+
+
+@pytest.mark.parametrize("x,y,s", [(1895, 369, 1865), (1085, 615, 2904)])
+def test_edge_on_thin_film_sample_stays_finite_like_the_reference(product, oracle, pkg, x, y, s):
+    """Two samples of BASELINE configs[2] (scene 10, 1920x1080, 4096 spp, MIS) at its TRUE size that round 3's first exact-hit build turned
+    into NaN pixels of the film (found by bench.py's film digest: mean = nan): a late vertex hits the thin-film hero edge-on (wo.z = -7e-9 in
+    the exact shading frame), the specular sample has f = 0 and pdf = NaN on both sides, and the next vertex is not a light.  The reference
+    adds T * SampledSpectrum::zero() there (base_renderer.rs:124-131) — an exact zero — and ends the path at the roulette (max of NaNs is
+    -inf, u < -inf fails); the kernel used to add T * ((f * 0) * (1 / pdf)) = NaN.  The whole tile of each sample over a window of sample
+    indices around it, production launch, against the oracle: finite, and the same radiance."""
+    W, H, S = 1920, 1080, 4096
+    sc, so = product.new_scene(), oracle.new_scene()
+    cam = pkg.scenes.load_scene(sc, 10, W, H, tex_size=64)
+    cam_o = pkg.scenes.load_scene(so, 10, W, H, tex_size=64)
+    oracle.set_faithful(so, False)
+    tiles_x = (W + 7) // 8
+    prm = pkg.make_params(S, "mis", "sobol", shard_index=(y // 8) * tiles_x + x // 8, shard_count=tiles_x * ((H + 7) // 8))
+    s0 = s - 8
+    L, lam, pdf = product.render_sample_log(sc, cam, prm, s0, s0 + 16)
+    assert L.shape[0] == 1 and np.isfinite(L).all()
+    pix = (y & 7) * 8 + (x & 7)
+    xys = np.stack([np.full(16, x), np.full(16, y), np.arange(s0, s0 + 16)], 1).astype(np.uint32)
+    Lc, lc, pc = so.probe_radiance(cam_o, pkg.make_params(S, "mis", "sobol"), xys)
+    assert np.array_equal(lam[0, pix], lc) and np.array_equal(pdf[0, pix], pc)
+    assert np.all(np.abs(L[0, pix] - Lc) <= 1e-3 * np.abs(Lc) + 1e-6)

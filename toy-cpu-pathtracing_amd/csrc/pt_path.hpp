@@ -438,13 +438,15 @@ PT_DEV bool shade_vertex_head(Path& P, const DevScene& sc, const DevParams& prm,
                     for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * ((pf[i] * Le[i]) * tf)) * w;
                 }
             } else if (prm.strategy != 1u || prev_spec) {
-                // The reference adds T * (f * 0 / pdf) * w even when the next vertex is not a light
-                // (pt_renderer.rs:43, mis_renderer.rs:163-180 with pdf_light = 0).  That is +0 unless the sample's
-                // pdf or throughput is inf/NaN (rough transmission at grazing half vectors), in which case it poisons
-                // the sample with NaN exactly like the CPU path; keep that behaviour bit for bit.
+                // The reference adds T * next_emissive_contribution * w even when the next vertex is not a light, and the contribution is
+                // then SampledSpectrum::zero() (base_renderer.rs:124-131) — an exact zero, NOT f * 0 / pdf (pt_renderer.rs:43,
+                // mis_renderer.rs:163-180 with pdf_light = 0).  That is +0 unless the throughput or the MIS weight is inf / NaN (rough
+                // transmission at grazing half vectors: pdf = inf), in which case it poisons the sample with NaN exactly like the CPU
+                // path; keep that behaviour bit for bit.  (Until round 3 this read (pf * 0) * tf: a specular sample with f = 0 and
+                // pdf = NaN — a thin-film hero hit edge-on, wo.z = -7e-9, two samples of C3's 8.5e9 — went NaN here and not in the reference.)
                 float w = (prm.strategy == 2u && !prev_spec) ? balance_heuristic(p_pdf, 0.0f) : 1.0f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * ((pf[i] * 0.0f) * tf)) * w;
+                for (int i = 0; i < 4; ++i) L[i] = L[i] + (T[i] * 0.0f) * w;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) T[i] = T[i] * (pf[i] * tf);
