@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""The linear films of the BASELINE configs at their TRUE size hold no non-finite value (GPU box only; C3 did for one build of round 3: two
+samples of 8.5e9, tests/test_parity_gpu.py::test_edge_on_thin_film_sample_stays_finite_like_the_reference)."""
 import importlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 pkg = importlib.import_module("toy-cpu-pathtracing_amd")

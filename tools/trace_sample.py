@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
+"""One sample's path vertices on both sides (GPU box only): the BSDF sample and the light connection of every vertex — wo, wi, f, pdf, the
+random numbers, the throughput — printed by the kernel (a variant built with -DPT_TRACE_MORTON=<(morton2(x, y) << log2 spp | s) as u32>u,
+tools/build_variant.sh; pt_path.hpp) and by the oracle (PTORACLE_TRACE=x,y,s).  The first number that differs is the root cause: this is how
+the six entries of DESIGN.md 2.1's table were found.
+usage: PTORACLE_TRACE=x,y,s MI355PT_LIB=build_variants/libmi355pt_<variant>.so tools/trace_sample.py <scene> <strategy> x y s <max_depth>"""
 import importlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 pkg = importlib.import_module("toy-cpu-pathtracing_amd")

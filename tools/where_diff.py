@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ad-hoc: which samples of a 64x48x64 frame differ between GPU and oracle, where on the frame, at which first depth"""
 import importlib, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 pkg = importlib.import_module("toy-cpu-pathtracing_amd")
