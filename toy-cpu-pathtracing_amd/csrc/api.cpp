@@ -847,7 +847,7 @@ int mi355pt_scene_export_bvh(const mi355pt_scene* s, void* out_nodes, uint32_t* 
     if (!s->impl.built) return fail(MI355PT_E_NOT_BUILT, "scene not built");
     const DevScene& d = s->impl.dev;
     if (out_nodes) { if (*n_nodes < d.n_nodes) return fail(MI355PT_E_INVALID, "node buffer too small"); if (d.n_nodes) HIP_TRY(hipMemcpy(out_nodes, d.nodes, sizeof(DevNode) * d.n_nodes, hipMemcpyDeviceToHost)); }
-    if (out_tris) { if (*n_tris < d.n_tris) return fail(MI355PT_E_INVALID, "triangle buffer too small"); HIP_TRY(hipMemcpy(out_tris, d.tris, sizeof(DevTri) * d.n_tris, hipMemcpyDeviceToHost)); }
+    if (out_tris) { if (*n_tris < d.n_tris) return fail(MI355PT_E_INVALID, "triangle buffer too small"); HIP_TRY(hipMemcpy(out_tris, d.tris_render, sizeof(DevTri) * d.n_tris, hipMemcpyDeviceToHost)); }
     *n_nodes = d.n_nodes; *n_tris = d.n_tris;
     if (root) *root = d.root;
     return MI355PT_OK;

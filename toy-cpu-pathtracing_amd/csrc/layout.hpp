@@ -91,8 +91,11 @@ PT_HD inline uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1; }
 struct alignas(16) DevTri {
     float p0[3]; float p1x;
     float p1yz[2]; float p2xy[2];
-    float p2z; uint32_t pad[3];   // pad[0]: sort class of the triangle's material (MT_* | 8 if it has a spectrum texture) — known with the hit, one dependent fetch before the shading record
-                                  // (the deferral queue sorts on it, pt_kernel.hpp PT_DEFER)
+    float p2z;
+    uint32_t instance;            // DevInstance index
+    uint32_t flags;               // bit 0: that instance is a pure translation (DevInstance::identity)
+    uint32_t mclass;              // sort class of the triangle's material (MT_* | 8 if it has a spectrum texture) - known with the hit, one dependent fetch before
+                                  // the shading record (the path queues sort on it, pt_kernel.hpp)
 };
 static_assert(sizeof(DevTri) == 48, "tri must be 48 B");
 
@@ -117,12 +120,7 @@ static_assert(sizeof(DevTriShade) == 112, "shade record must be 112 B");
 // last bit into other paths.  The traversal walks render-space triangles (DevTri); the ONE triangle it returns is intersected again the
 // reference's way (refine_hit, pt_path.hpp) with this record and the instance's two matrices, so that the shading point is the
 // reference's bit for bit.
-struct alignas(16) DevTriLocal {
-    float p0[3]; float p1x;        // LOCAL-space positions in the mesh's own vertex order
-    float p1yz[2]; float p2xy[2];
-    float p2z; uint32_t instance; uint32_t pad[2];   // pad[0]: DevInstance::identity of that instance (known before the instance record is read); pad[1] = DevTri::pad[0]
-};
-static_assert(sizeof(DevTriLocal) == 48, "local tri must be 48 B");
+using DevTriLocal = DevTri;    // the same record with LOCAL-space positions in the mesh's own vertex order
 
 struct alignas(16) DevInstance {
     float m[12];       // local_to_render: columns x, y, z, w (the xyz of each; the bottom row is 0 0 0 1)
@@ -215,6 +213,13 @@ struct DevScene {
     const DevTri* tris;
     const DevTriShade* shade;
     const DevTriLocal* tris_local; // leaf order, like tris / shade
+    const DevTri* tris_render;     // render-space positions (mi355pt_scene_export_bvh; = tris unless tris_are_local)
+    // When EVERY instance of the scene is the same pure translation (meshes placed with the identity: the Cornell scenes of BASELINE configs 1-4)
+    // the reference's local ray is the render ray with its origin shifted by one constant, for every primitive: `tris` then IS tris_local and
+    // every triangle test of every traversal runs on (origin + tri_shift, direction) - the reference's own test, any-hit included, and
+    // winner_hit has nothing left to redo.  Otherwise tri_shift = 0, tris = tris_render and winner_hit re-tests the one triangle found.
+    float tri_shift[3]; uint32_t tris_are_local;
+    float shared_mw[3]; uint32_t pad_mw;   // local_to_render's translation in that case (load_surface)
     const DevInstance* instances;
     const DevMaterial* materials;
     const DevLight* lights;

@@ -452,9 +452,13 @@ struct TriVerts { f3 p0, p1, p2; };
 PT_DEV TriVerts load_tri(const DevTri* tris, uint32_t i, uint32_t* mclass = nullptr) {
     const float4* q = (const float4*)(tris + i);
     float4 a = q[0], b = q[1], c = q[2];
-    if (mclass) *mclass = __float_as_uint(c.y);                       // DevTri::pad[0]: sort class of the triangle's material (layout.hpp)
+    if (mclass) *mclass = __float_as_uint(c.w);                       // DevTri::mclass: sort class of the triangle's material (layout.hpp)
     return TriVerts{mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x)};
 }
+
+// the origin every TRIANGLE test of a traversal uses (boxes use the render-space origin): shifted into the meshes' common local space when the
+// scene's triangle array holds local vertices (DevScene::tris_are_local), else + 0 (x + 0 is x)
+PT_DEV f3 tri_origin(const DevScene& sc, f3 o) { return o + mk3(sc.tri_shift[0], sc.tri_shift[1], sc.tri_shift[2]); }
 
 // returns true and (t, b0, b1, b2) when the ray hits within (0, t_max]
 PT_DEV bool intersect_triangle(f3 ro, f3 rd, int kx, int ky, int kz, float sx, float sy, float sz, float t_max, const TriVerts& tv,
@@ -543,8 +547,8 @@ PT_DEV TriVerts load_tri_local(const DevTriLocal* tris, uint32_t i, uint32_t* in
     const float4* q = (const float4*)(tris + i);
     const float4 a = q[0], b = q[1], c = q[2];
     *instance = __float_as_uint(c.y);
-    *identity = __float_as_uint(c.z) != 0u;                               // DevTriLocal::pad[0]: the instance is a translation (DevInstance::identity)
-    if (mclass) *mclass = __float_as_uint(c.w);                           // DevTriLocal::pad[1] = DevTri::pad[0]: sort class of the triangle's material
+    *identity = __float_as_uint(c.z) != 0u;                               // DevTri::flags bit 0: the instance is a translation (DevInstance::identity)
+    if (mclass) *mclass = __float_as_uint(c.w);                           // DevTri::mclass
     return TriVerts{mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x)};
 }
 // the translation columns alone (one 16-byte load each): all an identity instance needs
@@ -568,19 +572,21 @@ PT_DEV void winner_hit(const DevScene& sc, f3 ro, f3 rd, const RaySetup& rs, uin
     float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
     hit.tri = tri;
 #if PT_EXACT_HIT
-    uint32_t inst; bool ident;
-    const TriVerts tl = load_tri_local(sc.tris_local, tri, &inst, &ident, &hit.mclass);
-    f3 ol, dl;
-    if (ident) { ol = ro + load_instance_iw(sc.instances + inst); dl = rd; }   // 1 * a + 0 * b + 0 * c is a: the multiplies are exact
-    else { const InstXf x = load_instance(sc.instances + inst); ol = xf_point(x.ix, x.iy, x.iz, x.iw, ro); dl = xf_vector(x.ix, x.iy, x.iz, rd); }
-    const RaySetup ls = setup_ray(dl);
-    if (!intersect_triangle(ol, dl, ls.kx, ls.ky, ls.kz, ls.sx, ls.sy, ls.sz, 3.402823466e+38f, tl, t, b0, b1, b2))
-#else
-    (void)0;
+    bool done = false;
+    if (!sc.tris_are_local) {                                             // (wave-uniform: a kernel argument)
+        uint32_t inst; bool ident;
+        const TriVerts tl = load_tri_local(sc.tris_local, tri, &inst, &ident, &hit.mclass);
+        f3 ol, dl;
+        if (ident) { ol = ro + load_instance_iw(sc.instances + inst); dl = rd; }   // 1 * a + 0 * b + 0 * c is a: the multiplies are exact
+        else { const InstXf x = load_instance(sc.instances + inst); ol = xf_point(x.ix, x.iy, x.iz, x.iw, ro); dl = xf_vector(x.ix, x.iy, x.iz, rd); }
+        const RaySetup ls = setup_ray(dl);
+        done = intersect_triangle(ol, dl, ls.kx, ls.ky, ls.kz, ls.sx, ls.sy, ls.sz, 3.402823466e+38f, tl, t, b0, b1, b2);
+    }
+    if (!done)
 #endif
-    {
+    {   // the traversal's own test once more (same function, same inputs): in a tris_are_local scene that IS the reference's test
         const TriVerts tv = load_tri(sc.tris, tri, &hit.mclass);
-        intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
+        intersect_triangle(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
     }
     hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
 }
@@ -627,7 +633,7 @@ PT_DEV bool trace_closest(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_
                 TriVerts tv = load_tri(sc.tris, first + i);
                 float t, b0, b1, b2;
                 if (STATS) { st.tris_closest++; if (wave_leader()) st.w[1]++; }
-                if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
+                if (intersect_triangle(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
                     if (!found || t < t_best) { found = true; t_best = t; hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = first + i; }
                 }
             }
@@ -673,7 +679,7 @@ PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* s
                 TriVerts tv = load_tri(sc.tris, first + i);
                 float t, b0, b1, b2;
                 if (STATS) { st.tris_shadow++; if (wave_leader()) st.w[3]++; }
-                if (intersect_triangle(ro, rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_max, tv, t, b0, b1, b2)) return true;
+                if (intersect_triangle(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_max, tv, t, b0, b1, b2)) return true;
             }
         }
         if (sp == 0) break;
@@ -880,7 +886,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
         const bool valid = lane < n;
         const uint32_t e = valid ? L.ring[(head + lane) & (ANY_RING - 1u)] : (lane << 26);
         const uint32_t own = e >> 26, tri = e & 0x03ffffffu;
-        f3 o2 = mk3(__shfl(ro.x, own), __shfl(ro.y, own), __shfl(ro.z, own));
+        f3 o2 = tri_origin(sc, mk3(__shfl(ro.x, own), __shfl(ro.y, own), __shfl(ro.z, own)));
         f3 d2 = mk3(__shfl(rd.x, own), __shfl(rd.y, own), __shfl(rd.z, own));
         float tm = __shfl(t_max, own);
         uint32_t kp = __shfl(kpack, own);
@@ -1027,7 +1033,7 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
         const bool valid = lane < n;
         const uint32_t e = valid ? L.ring[(head + lane) & (ANY_RING - 1u)] : (lane << 26);
         const uint32_t own = e >> 26, tri = e & 0x03ffffffu;
-        f3 o2 = mk3(__shfl(ro.x, own), __shfl(ro.y, own), __shfl(ro.z, own));
+        f3 o2 = tri_origin(sc, mk3(__shfl(ro.x, own), __shfl(ro.y, own), __shfl(ro.z, own)));
         f3 d2 = mk3(__shfl(rd.x, own), __shfl(rd.y, own), __shfl(rd.z, own));
         uint32_t kp = __shfl(kpack, own);
         float sx = __shfl(rs.sx, own), sy = __shfl(rs.sy, own), sz = __shfl(rs.sz, own);
@@ -1267,7 +1273,7 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
         const float ssx = __shfl(srs.sx, own), ssy = __shfl(srs.sy, own), ssz = __shfl(srs.sz, own);
         const float stm = __shfl(s_tmax, own);
         if (valid) {
-            const f3 o2 = any ? so : co, d2 = any ? sd : cd;
+            const f3 o2 = tri_origin(sc, any ? so : co), d2 = any ? sd : cd;
             const uint32_t kp = any ? sk : ck;
             const float sx = any ? ssx : csx, sy = any ? ssy : csy, sz = any ? ssz : csz;
             const float t_lim = any ? stm : __uint_as_float((uint32_t)(L.best[own] >> 32));

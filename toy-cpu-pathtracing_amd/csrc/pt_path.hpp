@@ -112,7 +112,7 @@ PT_DEV Surface load_surface(const DevScene& sc, const Hit& h, f3 rd) {
         tg_l = generate_tangent(sn_l);
     }
     if (ident) {                                                                     // a translation: the 3x3 products are exact
-        s.p = p_l + load_instance_mw(sc.instances + inst);
+        s.p = p_l + (sc.tris_are_local ? mk3(sc.shared_mw[0], sc.shared_mw[1], sc.shared_mw[2]) : load_instance_mw(sc.instances + inst));   // (uniform)
         s.ng = normalize(ng_l); s.ns = normalize(sn_l); s.tangent = tg_l;
         s.wo = -rd;
     } else {

@@ -230,6 +230,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     std::vector<DevInstance> dinst(instances.size());
     std::vector<DevTri> tris_unordered;
     std::vector<DevTriLocal> local_unordered;
+    bool all_shared = true, have_shared = false;
+    float shared_iw[3] = {0, 0, 0}, shared_mw[3] = {0, 0, 0};
     std::vector<DevTriShade> shade_unordered;
     std::vector<BuildTri> btris;
     std::vector<DevLight> lights;
@@ -298,9 +300,16 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         mat4_inverse_glam(l2r, inv);
         for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) { di.m[3 * c + r] = l2r[4 * c + r]; di.inv[3 * c + r] = inv[4 * c + r]; }
         for (int k = 0; k < 12; ++k) if (!std::isfinite(di.inv[k])) { *err = "singular instance transform"; return MI355PT_E_INVALID; }
-        const float idm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        di.identity = (std::memcmp(di.m, idm, sizeof(idm)) == 0 && std::memcmp(di.inv, idm, sizeof(idm)) == 0) ? 1u : 0u;
+        // a pure translation: both 3x3 parts equal the identity NUMERICALLY (glam's inverse of a translation holds -0.0 in some off-diagonal
+        // entries; a * 1 + b * (-0) + c * 0 is still a, up to the sign of a zero, which no later operation can see)
+        di.identity = 1u;
+        for (int k = 0; k < 9; ++k) { const float e = (k % 4 == 0) ? 1.0f : 0.0f; if (!(di.m[k] == e) || !(di.inv[k] == e)) di.identity = 0u; }
+        if (getenv("MI355PT_NO_IDENTITY")) di.identity = 0u;                 // (A/B and tests: every instance through the general matrix path)
         di.pad[0] = di.pad[1] = di.pad[2] = 0;
+        // do all instances share ONE pure translation?  (DevScene::tris_are_local)
+        if (!di.identity) all_shared = false;
+        else if (!have_shared) { have_shared = true; std::memcpy(shared_iw, di.inv + 9, 12); std::memcpy(shared_mw, di.m + 9, 12); }
+        else if (std::memcmp(shared_iw, di.inv + 9, 12) != 0 || std::memcmp(shared_mw, di.m + 9, 12) != 0) all_shared = false;
         bool emissive = mat.type == MT_EMISSIVE;
         uint32_t light_index = ~0u;
         std::vector<float> area_list, area_table;
@@ -330,8 +339,9 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
                 // the rgb2spec lookup: the long branch).  Normal / roughness maps alone do not make a class: measured -4 % on scene 5.
                 const DevMaterial& dm = materials[inst.mat];
                 const bool tex = dm.color.kind == SPK_TEXTURE || dm.cc_tint.kind == SPK_TEXTURE || dm.eta.kind == SPK_TEXTURE;
-                dt.pad[0] = dm.type | (tex ? 8u : 0u);
+                dt.mclass = dm.type | (tex ? 8u : 0u);
             }
+            dt.instance = (uint32_t)ii; dt.flags = di.identity;
             tris_unordered.push_back(dt);
             BuildTri bt;
             for (int a = 0; a < 3; ++a) {
@@ -347,7 +357,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             DevTriLocal tl{};
             tl.p0[0] = pl[0].x; tl.p0[1] = pl[0].y; tl.p0[2] = pl[0].z; tl.p1x = pl[1].x;
             tl.p1yz[0] = pl[1].y; tl.p1yz[1] = pl[1].z; tl.p2xy[0] = pl[2].x; tl.p2xy[1] = pl[2].y; tl.p2z = pl[2].z;
-            tl.instance = (uint32_t)ii; tl.pad[0] = di.identity; tl.pad[1] = dt.pad[0];
+            tl.instance = (uint32_t)ii; tl.flags = di.identity; tl.mclass = dt.mclass;
             local_unordered.push_back(tl);
             const float* n0 = &mesh.nrm[3 * vi[0]]; const float* n1 = &mesh.nrm[3 * vi[1]]; const float* n2 = &mesh.nrm[3 * vi[2]];
             sh.n0[0] = n0[0]; sh.n0[1] = n0[1]; sh.n0[2] = n0[2]; sh.n1x = n1[0];
@@ -566,10 +576,15 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
 #endif
         bvh4_nodes = nodes4.size();
     }
-    if ((rc = upload(this, tris, &dev.tris, err))) return rc;
+    if ((rc = upload(this, tris, &dev.tris_render, err))) return rc;
     if ((rc = upload(this, shade, &dev.shade, err))) return rc;
     if ((rc = upload(this, dinst, &dev.instances, err))) return rc;
     if ((rc = upload(this, tris_local, &dev.tris_local, err))) return rc;
+    if (getenv("MI355PT_NO_LOCAL_TRIS")) all_shared = false;                 // (A/B and tests: force the general path)
+    dev.tris_are_local = (all_shared && have_shared) ? 1u : 0u;
+    dev.tris = dev.tris_are_local ? dev.tris_local : dev.tris_render;
+    for (int k = 0; k < 3; ++k) { dev.tri_shift[k] = dev.tris_are_local ? shared_iw[k] : 0.0f; dev.shared_mw[k] = dev.tris_are_local ? shared_mw[k] : 0.0f; }
+    dev.pad_mw = 0;
     {   // per clearcoat material: the coat's directional-albedo table (mi355pt_params.albedo_lut); the device copy of the material names its offset
         std::vector<float> cc_tab;
         std::vector<DevMaterial> mats = materials;
@@ -622,8 +637,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     }
     {
         char tail[224];
-        std::snprintf(tail, sizeof(tail), " builder=%s bvh_ms=%.2f bvh_device_ms=%.2f collapse=%s collapse_ms=%.2f stack_need=%d/%d", bvh_builder_used == MI355PT_BVH_GPU ? "gpu" : "host",
-                      bvh_build_ms, bvh_device_ms, collapse_method, collapse_ms, bvh4_stack_need, STACK_DEPTH);
+        std::snprintf(tail, sizeof(tail), " builder=%s bvh_ms=%.2f bvh_device_ms=%.2f collapse=%s collapse_ms=%.2f stack_need=%d/%d tri_space=%s", bvh_builder_used == MI355PT_BVH_GPU ? "gpu" : "host",
+                      bvh_build_ms, bvh_device_ms, collapse_method, collapse_ms, bvh4_stack_need, STACK_DEPTH, dev.tris_are_local ? "local" : "render");
         info = "nodes4=" + std::to_string(bvh4_nodes) + " nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth) + tail;
     }
     built = true;
