@@ -15,6 +15,12 @@ extern "C" {
  * mi355pt_debug_unlock(1) and refused otherwise.  Process-wide; mi355pt_debug_unlock(0) locks again.  Returns the previous state. */
 int mi355pt_debug_unlock(int on);
 
+/* How the next mi355pt_scene_build lowers the instances (A/B runs and tests; the three paths must give the reference's hit alike):
+ * 0 (default) the triangle array holds LOCAL vertices when every instance is the same pure translation - every triangle test of every
+ *   traversal is then the reference's (primitive/impls/triangle_mesh.rs:89-119) - else render-space triangles and the triangle found is
+ *   intersected again in its mesh's local space; 1 never the local array; 2 in addition every instance through the full matrix path. */
+int mi355pt_scene_debug_set_lowering(mi355pt_scene* s, int mode);
+
 /* ---------------- probes (parity tests; same device code as the render path) ---------------- */
 /* The built acceleration structure as the device holds it (no reference counterpart; the reference's is scene/src/bvh.rs:300-343):
  * node records of 64 B {bx[4] = lo0.x lo1.x hi0.x hi1.x, by[4], bz[4], int32 child[2] (>= 0 node index, < 0 leaf:

@@ -237,9 +237,10 @@ struct PathTracer {
     SS trace(uint32_t px, uint32_t py, uint32_t sample_index, Wavelengths* wl_out, Counters* c, uint32_t* flags = nullptr) const {
         Sampler smp = Sampler::create((int)prm.sampler, prm.spp, prm.width, prm.height, prm.seed);
         smp.start_pixel_sample(px, py, sample_index, prm.width);
-        if (const char* tr = std::getenv("PTORACLE_TRACE")) {   // "x,y,s": print the light connections of that sample (debugging aid)
-            unsigned tx = 0, ty = 0, ts = 0;
-            g_trace_on = std::sscanf(tr, "%u,%u,%u", &tx, &ty, &ts) == 3 && tx == px && ty == py && ts == sample_index;
+        {   // PTORACLE_TRACE="x,y,s": print the BSDF samples and light connections of that sample (debugging aid, tools/trace_sample.py); read once
+            static const struct TraceTarget { bool on = false; unsigned x = 0, y = 0, s = 0;
+                                              TraceTarget() { if (const char* tr = std::getenv("PTORACLE_TRACE")) on = std::sscanf(tr, "%u,%u,%u", &x, &y, &s) == 3; } } target;
+            g_trace_on = target.on && target.x == px && target.y == py && target.s == sample_index;
         }
         SS T = SS::one(), L = SS::zero();
         float u = smp.get_1d();

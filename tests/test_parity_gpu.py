@@ -548,7 +548,10 @@ def test_baseline_configs_at_true_size_match_the_oracle(product, oracle, pkg, na
     rg, rc = oracle.film_resolve(film_g[mask], spp), oracle.film_resolve(film_c[mask], spp)
     rmse = float(np.sqrt(np.mean((rg - rc) ** 2)))
     off = int((np.abs(rg - rc).max(axis=1) > 0.01).sum())
-    assert film_c[mask].mean() > 0.01 * spp and rmse <= 5e-4 and off <= 2, (rmse, off)
+    if os.environ.get("MI355PT_FRAME_LOG"):
+        with open(os.environ["MI355PT_FRAME_LOG"], "a") as f:
+            f.write(f'{{"config": "{name}", "true_size_shard_rmse": {rmse:.3e}, "off": {off}}}\n')
+    assert film_c[mask].mean() > 0.01 * spp and rmse <= 1.5e-4 and off == 0, (rmse, off)      # (round 2: 5e-4 and <= 2 pixels)
     # the log's film is the film: summing the logged samples' sensor responses is what add_sample did (spot check through the oracle's resolve
     # is not possible per sample, so compare per-sample radiance instead)
     rng = np.random.default_rng(spp + scene_id)
@@ -766,20 +769,18 @@ def test_edge_on_thin_film_sample_stays_finite_like_the_reference(product, oracl
 
 
 @pytest.mark.parametrize("scene_id,strategy", [(3, "mis"), (4, "mis"), (8, "nee")])
-def test_lowering_paths_agree_with_the_oracle(product, oracle, pkg, scene_id, strategy, monkeypatch):
-    """The three ways the product rebuilds the reference's local-space hit (csrc/scene.cpp picks one per scene / instance):
+def test_lowering_paths_agree_with_the_oracle(product, oracle, pkg, scene_id, strategy):
+    """The three ways the product rebuilds the reference's local-space hit (csrc/scene.cpp picks one per scene / instance;
+    mi355pt_scene_debug_set_lowering forces the fallbacks):
       local     every instance is the same pure translation: the triangle array holds local vertices, every triangle test of every traversal
                 runs on the reference's local ray (scene_info: tri_space=local) — what the Cornell-class BASELINE scenes take;
-      identity  render-space traversal, the triangle found re-tested in local space, translation instances skip the 3x3 products (MI355PT_NO_LOCAL_TRIS);
-      general   the same with every instance through the full matrix path (+ MI355PT_NO_IDENTITY) — what scaled / rotated heroes take.
+      identity  render-space traversal, the triangle found re-tested in local space, translation instances skip the 3x3 products;
+      general   the same with every instance through the full matrix path — what scaled / rotated heroes take.
     All three must trace the oracle's paths (frame bar), and identity == general bit for bit (1 * a + 0 * b + 0 * c is a)."""
     frames = {}
-    for mode, env in (("local", {}), ("identity", {"MI355PT_NO_LOCAL_TRIS": "1"}), ("general", {"MI355PT_NO_LOCAL_TRIS": "1", "MI355PT_NO_IDENTITY": "1"})):
-        for k in ("MI355PT_NO_LOCAL_TRIS", "MI355PT_NO_IDENTITY"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for mode, lowering in (("local", "auto"), ("identity", "no_local_tris"), ("general", "general")):
         sc = product.new_scene()
+        sc.debug_set_lowering(lowering)
         cam = pkg.scenes.load_scene(sc, scene_id, 64, 48, tex_size=128)
         assert ("tri_space=local" in product.scene_info(sc)) == (mode == "local")
         frames[mode] = product.render(sc, cam, pkg.make_params(64, strategy, "sobol"))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Share of the 196 608 samples of a 64x48x64-spp frame whose spectral radiance is BIT-EQUAL on GPU and oracle, and the largest relative
 difference among the rest (GPU box only).  usage: tools/bit_equal_share.py <scene>:<strategy> ...
-MI355PT_NO_LOCAL_TRIS=1 / MI355PT_NO_IDENTITY=1 select the product's general lowering paths (scene.cpp)."""
+LOWERING=auto|no_local_tris|general selects the product's lowering path (mi355pt_scene_debug_set_lowering)."""
 import importlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -14,7 +14,7 @@ ys, xs, ss = np.meshgrid(np.arange(H), np.arange(W), np.arange(S), indexing="ij"
 xys = np.stack([xs.ravel(), ys.ravel(), ss.ravel()], 1).astype(np.uint32)
 for arg in sys.argv[1:]:
     sid, strat = arg.split(":"); sid = int(sid)
-    gsc = prod.new_scene(); gcam = pkg.scenes.load_scene(gsc, sid, W, H, tex_size=128)
+    gsc = prod.new_scene(); gsc.debug_set_lowering(os.environ.get("LOWERING", "auto")); gcam = pkg.scenes.load_scene(gsc, sid, W, H, tex_size=128)
     osc = orc.new_scene(); ocam = pkg.scenes.load_scene(osc, sid, W, H, tex_size=128); orc.set_faithful(osc, False)
     prm = pkg.make_params(S, strat, "sobol")
     Lg, lg, pg = gsc.probe_radiance(gcam, prm, xys)

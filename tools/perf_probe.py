@@ -24,6 +24,7 @@ ap.add_argument("--tag", default="")
 ap.add_argument("--max-depth", type=int, default=16)
 ap.add_argument("--shards", type=int, default=1, help="render only shard 0 of N (emulates one rank of an N-GPU job)")
 ap.add_argument("--tex-size", type=int, default=1024)
+ap.add_argument("--lowering", default="auto", help="mi355pt_scene_debug_set_lowering: auto | no_local_tris | general")
 ap.add_argument("--no-stats", action="store_true", help="skip the instrumented launch (PC sampling wants only the production kernel)")
 a = ap.parse_args()
 
@@ -31,6 +32,7 @@ pkg = importlib.import_module("toy-cpu-pathtracing_amd")
 import ctypes as C
 prod = pkg.Product()
 sc = prod.new_scene()
+sc.debug_set_lowering(a.lowering)
 cam = pkg.scenes.load_scene(sc, a.scene, a.width, a.height, tex_size=a.tex_size)
 hip = C.CDLL("libamdhip64.so")
 n = a.width * a.height * 3 * 4

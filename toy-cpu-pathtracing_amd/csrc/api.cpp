@@ -424,6 +424,12 @@ int mi355pt_scene_set_bvh_builder(mi355pt_scene* s, int mode) {
     s->impl.bvh_builder = mode;
     return MI355PT_OK;
 }
+int mi355pt_scene_debug_set_lowering(mi355pt_scene* s, int mode) {
+    if (!s) return fail(MI355PT_E_INVALID, "null argument");
+    if (mode < 0 || mode > 2) return fail(MI355PT_E_INVALID, "unknown lowering mode");
+    s->impl.lowering = mode;
+    return MI355PT_OK;
+}
 int mi355pt_scene_build(mi355pt_scene* s, const mi355pt_camera* cam) {
     if (!s || !cam) return fail(MI355PT_E_INVALID, "null argument");
     std::string err;
@@ -631,7 +637,7 @@ int mi355pt_scene_build_multi(mi355pt_scene* s, const mi355pt_camera* cam, int n
             if (!m.scene) { rc = fail(MI355PT_E_INVALID, "allocation failed"); break; }
             SceneImpl& d = m.scene->impl; const SceneImpl& o = s->impl;       // the description, not the lowered state
             d.table = o.table; d.luts = o.luts; d.textures = o.textures; d.meshes = o.meshes; d.mat_descs = o.mat_descs; d.materials = o.materials;
-            d.instances = o.instances; d.envs = o.envs; d.delta_lights = o.delta_lights; d.bvh_builder = o.bvh_builder;
+            d.instances = o.instances; d.envs = o.envs; d.delta_lights = o.delta_lights; d.bvh_builder = o.bvh_builder; d.lowering = o.lowering;
         }
         rc = mi355pt_scene_build(m.scene, cam);
         if (rc == MI355PT_OK && hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) != hipSuccess) rc = fail(MI355PT_E_DEVICE, "hipStreamCreate failed");

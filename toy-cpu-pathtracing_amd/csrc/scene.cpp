@@ -304,7 +304,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
         // entries; a * 1 + b * (-0) + c * 0 is still a, up to the sign of a zero, which no later operation can see)
         di.identity = 1u;
         for (int k = 0; k < 9; ++k) { const float e = (k % 4 == 0) ? 1.0f : 0.0f; if (!(di.m[k] == e) || !(di.inv[k] == e)) di.identity = 0u; }
-        if (getenv("MI355PT_NO_IDENTITY")) di.identity = 0u;                 // (A/B and tests: every instance through the general matrix path)
+        if (lowering >= 2) di.identity = 0u;                                 // (mi355pt_scene_debug_set_lowering: every instance through the general matrix path)
         di.pad[0] = di.pad[1] = di.pad[2] = 0;
         // do all instances share ONE pure translation?  (DevScene::tris_are_local)
         if (!di.identity) all_shared = false;
@@ -580,7 +580,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     if ((rc = upload(this, shade, &dev.shade, err))) return rc;
     if ((rc = upload(this, dinst, &dev.instances, err))) return rc;
     if ((rc = upload(this, tris_local, &dev.tris_local, err))) return rc;
-    if (getenv("MI355PT_NO_LOCAL_TRIS")) all_shared = false;                 // (A/B and tests: force the general path)
+    if (lowering >= 1) all_shared = false;                                   // (mi355pt_scene_debug_set_lowering: A/B and tests)
     dev.tris_are_local = (all_shared && have_shared) ? 1u : 0u;
     dev.tris = dev.tris_are_local ? dev.tris_local : dev.tris_render;
     for (int k = 0; k < 3; ++k) { dev.tri_shift[k] = dev.tris_are_local ? shared_iw[k] : 0.0f; dev.shared_mw[k] = dev.tris_are_local ? shared_mw[k] : 0.0f; }

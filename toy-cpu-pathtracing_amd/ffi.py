@@ -120,7 +120,7 @@ def _ptr(a, ty):
 
 
 # every symbol include/mi355pt.h declares (tests/test_abi.py checks the built library exports all of them) ...
-DEBUG_SYMBOLS = ["debug_unlock", "scene_export_bvh", "probe_bvh_collapse", "probe_bvh_collapse_nodes", "probe_sobol", "probe_sincos", "probe_intersect", "probe_occluded",
+DEBUG_SYMBOLS = ["debug_unlock", "scene_debug_set_lowering", "scene_export_bvh", "probe_bvh_collapse", "probe_bvh_collapse_nodes", "probe_sobol", "probe_sincos", "probe_intersect", "probe_occluded",
                  "sample_log_records", "render_sample_log", "probe_radiance"]     # ... and include/mi355pt_debug.h
 ABI_SYMBOLS = [
     "scene_create", "scene_destroy", "scene_set_rgb2spec", "scene_add_lut470", "scene_add_tex_rgb8", "scene_add_mesh",
@@ -279,6 +279,12 @@ class SceneHandle:
         fn = self.b.fn("scene_set_bvh_builder")
         fn.argtypes = [C.c_void_p, C.c_int]
         self.b.check(fn(self.h, {"auto": 0, "host": 1, "gpu": 2}[mode]), "scene_set_bvh_builder")
+
+    def debug_set_lowering(self, mode):
+        """mi355pt_scene_debug_set_lowering (include/mi355pt_debug.h): "auto" | "no_local_tris" | "general" (product only)."""
+        fn = self.b.fn("scene_debug_set_lowering")
+        fn.argtypes = [C.c_void_p, C.c_int]
+        self.b.check(fn(self.h, {"auto": 0, "no_local_tris": 1, "general": 2}[mode]), "scene_debug_set_lowering")
 
     def build(self, cam):
         self.b.check(self.b.fn("scene_build")(self.h, C.byref(cam)), "scene_build")
