@@ -155,8 +155,12 @@ struct PathTracer {
         MaterialEval me{scene, c};
         me.mc_key = mc_key;   // same inner Monte-Carlo stream as the vertex's sample() call
         SS f = me.evaluate(mat, wl, wo, wi, spt);
-        if (g_trace_on) std::fprintf(stderr, "[oracle] nee wo=(%.9g %.9g %.9g) wi=(%.9g %.9g %.9g) f0=%.9g pdf_dir=%.9g pdf_bsdf=%.9g rad0=%.9g\n", wo.x, wo.y, wo.z, wi.x, wi.y, wi.z,
-                                     f.v[0], rad.pdf_dir, me.pdf(mat, wl, wo, wi, spt), rad.radiance.v[0]);
+        if (g_trace_on) {
+            V3 ln_ = transform_normal(r2t, rad.light_normal);
+            std::fprintf(stderr, "[oracle] nee wo=(%.9g %.9g %.9g) wi=(%.9g %.9g %.9g) f=(%.9g %.9g %.9g %.9g) pdf_dir=%.9g pdf_bsdf=%.9g rad=(%.9g %.9g %.9g %.9g) g=%.9g den=%.9g\n", wo.x, wo.y, wo.z, wi.x, wi.y, wi.z,
+                         f.v[0], f.v[1], f.v[2], f.v[3], rad.pdf_dir, me.pdf(mat, wl, wo, wi, spt), rad.radiance.v[0], rad.radiance.v[1], rad.radiance.v[2], rad.radiance.v[3],
+                         std::fabs(dot(ln_, -wi)) / length_squared(dv), rad.pdf * light_prob);
+        }
         float distance2 = length_squared(dv);
         V3 ln = transform_normal(r2t, rad.light_normal);
         float cos_light = std::fabs(dot(ln, -wi));

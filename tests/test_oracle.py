@@ -251,3 +251,4 @@ def test_device_sincos_restatement_equals_the_host_libm(tmp_path):
     assert r.returncode == 0, out
     assert out["compared"] >= 36_000_000 and out["sin_mismatches"] == 0 and out["cos_mismatches"] == 0
     assert out["libm_sincosf_differs_from_sinf_cosf"] == 0 and out["out_of_range_refused"] is True
+    assert out["exp_compared"] >= 36_000_000 and out["exp_mismatches"] <= 2      # expf_glibc (the optional bit-exact sigmoid, PT_SIGMOID_EXACT)

@@ -16,7 +16,7 @@ for arg in sys.argv[1:]:
     sid, strat = arg.split(":"); sid = int(sid)
     gsc = prod.new_scene(); gsc.debug_set_lowering(os.environ.get("LOWERING", "auto")); gcam = pkg.scenes.load_scene(gsc, sid, W, H, tex_size=128)
     osc = orc.new_scene(); ocam = pkg.scenes.load_scene(osc, sid, W, H, tex_size=128); orc.set_faithful(osc, False)
-    prm = pkg.make_params(S, strat, "sobol")
+    prm = pkg.make_params(S, strat, "sobol", max_depth=int(os.environ.get("MAX_DEPTH", "16")))
     Lg, lg, pg = gsc.probe_radiance(gcam, prm, xys)
     Lc, lc, pc = osc.probe_radiance(ocam, prm, xys)
     same = np.all((Lg.view(np.uint32) == Lc.view(np.uint32)) | (np.isnan(Lg) & np.isnan(Lc)), axis=1)
@@ -24,4 +24,5 @@ for arg in sys.argv[1:]:
         rel = np.nan_to_num(np.abs(Lg - Lc) / np.maximum(np.abs(Lc), 1e-12))[~same]
     print(json.dumps({"scene": sid, "strategy": strat, "tri_space": prod.scene_info(gsc).split("tri_space=")[-1], "bit_equal_share": round(float(same.mean()), 6),
                       "not_equal": int((~same).sum()), "median_rel_diff_of_those": float(np.median(rel)) if rel.size else 0.0,
-                      "over_1e-3": int((rel.max(axis=1) > 1e-3).sum()) if rel.size else 0}), flush=True)
+                      "over_1e-3": int((rel.max(axis=1) > 1e-3).sum()) if rel.size else 0,
+                      "first_not_equal": [(xys[i].tolist(), Lg[i].tolist(), Lc[i].tolist()) for i in np.nonzero(~same)[0][:3]] if os.environ.get("SHOW") else None}), flush=True)

@@ -278,12 +278,21 @@ PT_DEV float lut_value(const float* lut, float lambda) {                 // dens
     int idx = (int)floorf(lambda - LAMBDA_MIN);
     return idx < 470 ? lut[idx] : 0.0f;
 }
+// PT_SIGMOID_EXACT 1: the reference's expression with the host libm's expf restated in double (and the division by 470): every albedo / emission
+// value bit-equal to the reference's.  Default 0 - see DESIGN.md 2.1 for the measured share of bit-equal samples and the cost.
+#ifndef PT_SIGMOID_EXACT
+#define PT_SIGMOID_EXACT 0
+#endif
 PT_DEV float sigmoid_value(float c0, float c1, float c2, float lambda) {   // rgb_sigmoid_polynomial.rs:17-23,179-182
-    float t = (lambda - LAMBDA_MIN) * (1.0f / (LAMBDA_MAX - LAMBDA_MIN));   // the reference divides by 470: <= 1 ulp apart, albedo values only
+    float t = PT_SIGMOID_EXACT ? (lambda - LAMBDA_MIN) / (LAMBDA_MAX - LAMBDA_MIN) : (lambda - LAMBDA_MIN) * (1.0f / (LAMBDA_MAX - LAMBDA_MIN));   // the reference divides by 470: <= 1 ulp apart, albedo values only
     float x = t * t * c0 + t * c1 + c2;
     // 1 / (1 + exp(-x)) (rgb_sigmoid_polynomial.rs:18-20) through the hardware exp2 and reciprocal: a reflectance / emission
     // value, relative error < 1e-6 for the |x| < 50 the table produces; the correctly rounded form costs ~26 VALU instructions
     // more, 16 times per sample
+#if PT_SIGMOID_EXACT
+    float e;
+    if (ptlibm::expf_glibc(-x, &e)) return 1.0f / (1.0f + e);          // the reference's own 1.0 / (1.0 + (-x).exp()) (f32::exp = the host's expf, pt_libm.hpp)
+#endif
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 // (float)c / 255.0f for c = 0..255, correctly rounded at compile time: a load (the memory pipes are idle) instead of the ~10 VALU

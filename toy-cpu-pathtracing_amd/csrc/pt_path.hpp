@@ -33,6 +33,14 @@ PT_DEV Frame shading_frame(f3 shading_normal, f3 tangent) {
 // product (Oracle.set_render_space_lowering; alone: 0.216 % / 0.076 % / 0.045 %) 0.053 % / 0.018 % / 0.002 %: the two roundings COMPOUND, and
 // a fifth of the flips has yet another source.  Cost: -1.2...-1.3 % on the dielectric kernels (scenes 8 / 9 / 10), -5.7 % on C2's kernel if
 // applied everywhere.  It does not by itself let the solid-plastic frames pass with the reference's gate, so it is not the default.
+// PT_EXACT_DIV 1: the divisions of the light connection and of the sensor are the reference's divisions; 0 (default): a reciprocal shared by the
+// four wavelengths, x * (1 / PI) and the like (<= 1 ulp each: no path decision hangs on them, but half of the samples' radiance then differs
+// from the reference's in its last bit).  Together with PT_SIGMOID_EXACT (pt_device.hpp) this is the BIT-EXACT build: measured share of
+// samples whose spectral radiance equals the oracle's bit for bit 0.50 -> 0.83 (this macro, -0.6 %) -> 0.9999 (both, -2.2 ... 2.8 % more) on
+// untextured scenes; profiles/r03_bit_exact_options.log, DESIGN.md 2.1.
+#ifndef PT_EXACT_DIV
+#define PT_EXACT_DIV 0
+#endif
 #ifndef PT_FRAME_INVERSE
 #define PT_FRAME_INVERSE 2
 #endif
@@ -1030,9 +1038,10 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                         }
                     } else if (!(FEAT & FEAT_CC) || nee_kind == 1u) {                                     // LambertMaterial::{evaluate,pdf} (lambert_material.rs:99-159)
                         if (sgn1(gwi) == sgn1(geo_wo) && wo_nm.z != 0.0f && wi_nm.z != 0.0f && sgn1(wo_nm.z) == sgn1(wi_nm.z)) {
-                            pdf_b = fabsf(wi_nm.z) * INV_PI_F;
+                            // (lambert.rs: albedo * |cos| / PI.  PT_EXACT_DIV 0 multiplies by 1 / PI instead: <= 1 ulp apart)
+                            pdf_b = PT_EXACT_DIV ? fabsf(wi_nm.z) / PI_F : fabsf(wi_nm.z) * INV_PI_F;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) fl[i] = (albedo[i] * fabsf(wi_nm.z)) * INV_PI_F;
+                            for (int i = 0; i < 4; ++i) fl[i] = PT_EXACT_DIV ? (albedo[i] * fabsf(wi_nm.z)) / PI_F : (albedo[i] * fabsf(wi_nm.z)) * INV_PI_F;
                         }
                     } else {                                                  // SimpleClearcoatPbrMaterial::{evaluate,pdf} (:261-433)
                         float dgc, p5c, pdfc, dgb, p5b, pdfb;
@@ -1087,13 +1096,13 @@ PT_DEV bool shade_vertex_tail(Path& P, const DevScene& sc, const DevParams& prm,
                     float wgt = prm.strategy == 2u ? balance_heuristic(pdf_dir, pdf_b) : 1.0f;
                     sh_d = wi_r; sh_o = sf.p + wi_r * SHADOW_EPS; sh_t = length(dv) - 2.0f * SHADOW_EPS;
 #ifdef PT_TRACE_MORTON
-                    if (smp.morton == PT_TRACE_MORTON) printf("[gpu] nee depth=%u wo=(%.9g %.9g %.9g) wi=(%.9g %.9g %.9g) f0=%.9g pdf_dir=%.9g pdf_bsdf=%.9g rad0=%.9g alpha=%.9g kind=%u\n", P.depth, wo_nm.x, wo_nm.y, wo_nm.z,
-                                                              wi_nm.x, wi_nm.y, wi_nm.z, fl[0], pdf_dir, pdf_b, lrad[0] * l_inten, C.d_alpha, nee_kind);
+                    if (smp.morton == PT_TRACE_MORTON) printf("[gpu] nee depth=%u wo=(%.9g %.9g %.9g) wi=(%.9g %.9g %.9g) f=(%.9g %.9g %.9g %.9g) pdf_dir=%.9g pdf_bsdf=%.9g rad=(%.9g %.9g %.9g %.9g) g=%.9g den=%.9g T=(%.9g %.9g %.9g %.9g) alpha=%.9g kind=%u\n", P.depth, wo_nm.x, wo_nm.y, wo_nm.z,
+                                                              wi_nm.x, wi_nm.y, wi_nm.z, fl[0], fl[1], fl[2], fl[3], pdf_dir, pdf_b, lrad[0] * l_inten, lrad[1] * l_inten, lrad[2] * l_inten, lrad[3] * l_inten, g, pdf_a * lprob, T[0], T[1], T[2], T[3], C.d_alpha, nee_kind);
 #endif
-                    const float rden = 1.0f / (pdf_a * lprob);   // one division for the four wavelengths (<= 1 ulp from x / (pdf_a * lprob))
+                    const float rden = 1.0f / (pdf_a * lprob);   // PT_EXACT_DIV 0: one division for the four wavelengths (<= 1 ulp from x / (pdf_a * lprob))
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        sh_c[i] = (T[i] * (((fl[i] * (lrad[i] * l_inten)) * g) * rden)) * wgt;
+                        sh_c[i] = (T[i] * (PT_EXACT_DIV ? (((fl[i] * (lrad[i] * l_inten)) * g) / (pdf_a * lprob)) : (((fl[i] * (lrad[i] * l_inten)) * g) * rden))) * wgt;
                     }
                 }
             }
@@ -1149,7 +1158,7 @@ PT_DEV void film_rgb(const Path& P, const DevScene& sc, const DevParams& prm, fl
             // sensor.rs:52-66 divides by the wavelength pdf (1/470, or 1/1880 for a terminated sample) and by 4: the pdf is one of two
             // constants, so its reciprocal is folded at compile time (<= 1 ulp from L / pdf)
             const float inv_pdf = wl.term ? 1.0f / (pdf0 / 4.0f) : 1.0f / pdf0;
-            float c = (L[k] * inv_pdf) / 4.0f;
+            float c = PT_EXACT_DIV ? (L[k] / (wl.term ? pdf0 / 4.0f : pdf0)) / 4.0f : (L[k] * inv_pdf) / 4.0f;
             float4 m = cmf[idx];
             X += c * m.x; Y += c * m.y; Z += c * m.z;
         }
