@@ -315,6 +315,12 @@ def test_other_scenes_radiance_parity(product, oracle, pkg, scene_id, strategy):
         with open(os.environ["MI355PT_PARITY_LOG"], "a") as f:
             f.write(f'{{"scene": {scene_id}, "strategy": "{strategy}", "close": {close.mean():.6f}, "same_term": {same_term.mean():.6f}}}\n')
     assert close.mean() >= PER_SAMPLE_MIN, close.mean()
+    # ... and two orders of magnitude tighter: the same paths, so the radiance agrees to the rounding of a few operations.  Measured
+    # (tools/ulp_hist.py, profiles/r03_ulp_hist.jsonl): half of the samples bit-equal, 96 % within 1e-6, >= 99.95 % within 1e-5 (scene 19,
+    # whose every sample reads the environment map through atan2f / acosf: 99.84 %; scene 29 with its two maps: 99.64 %)
+    with np.errstate(invalid="ignore"):
+        tight = np.all((np.abs(Lg - Lc) <= 1e-5 * np.abs(Lc) + 1e-12) | (np.isnan(Lg) & np.isnan(Lc)), axis=1)
+    assert tight.mean() >= (0.995 if scene_id == 29 else 0.997), tight.mean()
     # The reference accumulates NaN samples without complaint (sensor.rs:42 only logs).  Rough SF11 glass under MIS makes
     # some: below 370 nm the eta LUT is 0 -> eta' = 1 (dielectric.rs:144-148), the "refracted" ray is -wo, and whenever
     # dot(wi,wm) + dot(wo,wm) rounds to exactly 0 the sample has f = 0 (spectrum / 0 -> 0), pdf = inf and the MIS weight
