@@ -109,8 +109,9 @@ struct alignas(16) DevTriShade {
     uint32_t light;                // light index if emissive else ~0
     uint32_t local_tri;            // triangle index inside its mesh
     float light_pdf_area;          // (1/area_i) * (cdf_i - cdf_{i-1}) for emissive tris (emissive_triangle_mesh.rs:334-353)
-    float ng[3]; uint32_t pad_ng;  // LOCAL-space geometric normal, normalize(normalize(cross(p1-p0, p2-p0))) (ray.rs:167-174): a function of
-                                   // the triangle alone, computed once by the host with the arithmetic of the device code it replaces
+    float ng[3]; uint32_t pad_ng;  // RENDER-space geometric normal the reference's way: normalize(normalize(cross(p1-p0, p2-p0))) of the LOCAL vertices
+                                   // (ray.rs:167-174) carried through Transform * Normal (samples.rs:135) - a function of the triangle alone,
+                                   // computed once by the host with the arithmetic of the device code it replaces
 };
 static_assert(sizeof(DevTriShade) == 112, "shade record must be 112 B");
 

@@ -104,7 +104,7 @@ PT_DEV Surface load_surface(const DevScene& sc, const Hit& h, f3 rd) {
     const f3 p_l = tv.p0 * h.b0 + tv.p1 * h.b1 + tv.p2 * h.b2;                       // ray.rs:161-165, in LOCAL space
     const float4* q = (const float4*)(sc.shade + h.tri);
     float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
-    const f3 ng_l = mk3(g.x, g.y, g.z);                                              // ray.rs:167-174, precomputed per triangle (layout.hpp)
+    s.ng = mk3(g.x, g.y, g.z);                                                       // ray.rs:167-174 + samples.rs:135, precomputed per triangle (layout.hpp)
     f3 n0 = mk3(a.x, a.y, a.z), n1 = mk3(a.w, b.x, b.y), n2 = mk3(b.z, b.w, c.x);
     f3 tan_l = mk3(c.y, c.z, c.w);
     s.material = __float_as_uint(e.z);
@@ -121,12 +121,12 @@ PT_DEV Surface load_surface(const DevScene& sc, const Hit& h, f3 rd) {
     }
     if (ident) {                                                                     // a translation: the 3x3 products are exact
         s.p = p_l + (sc.tris_are_local ? mk3(sc.shared_mw[0], sc.shared_mw[1], sc.shared_mw[2]) : load_instance_mw(sc.instances + inst));   // (uniform)
-        s.ng = normalize(ng_l); s.ns = normalize(sn_l); s.tangent = tg_l;
+        s.ns = normalize(sn_l); s.tangent = tg_l;
         s.wo = -rd;
     } else {
         const InstXf x = load_instance(sc.instances + inst);
         s.p = xf_point(x.mx, x.my, x.mz, x.mw, p_l);
-        s.ng = xf_normal(x, ng_l); s.ns = xf_normal(x, sn_l);
+        s.ns = xf_normal(x, sn_l);
         s.tangent = xf_vector(x.mx, x.my, x.mz, tg_l);
         s.wo = xf_vector(x.mx, x.my, x.mz, -xf_vector(x.ix, x.iy, x.iz, rd));
     }

@@ -353,7 +353,15 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             DevTriShade sh{};
             V3 pl[3];
             for (int k = 0; k < 3; ++k) pl[k] = V3{mesh.pos[3 * vi[k]], mesh.pos[3 * vi[k] + 1], mesh.pos[3 * vi[k] + 2]};
-            { V3 g = normalize(normalize(cross(pl[1] - pl[0], pl[2] - pl[0]))); sh.ng[0] = g.x; sh.ng[1] = g.y; sh.ng[2] = g.z; sh.pad_ng = 0; }   // LOCAL (ray.rs:167-174)
+            {   // the hit's geometric normal is a function of the triangle alone: ray.rs:167-174 in LOCAL space, then Transform * Normal
+                // (samples.rs:135, transform.rs:45-51: transpose(inverse) * n, renormalised) - computed here once with the arithmetic of the
+                // device code it replaces (xf_normal, pt_device.hpp; a translation leaves normalize(n))
+                V3 g = normalize(normalize(cross(pl[1] - pl[0], pl[2] - pl[0])));
+                if (!di.identity)
+                    g = V3{(di.inv[0] * g.x + di.inv[1] * g.y) + di.inv[2] * g.z, (di.inv[3] * g.x + di.inv[4] * g.y) + di.inv[5] * g.z, (di.inv[6] * g.x + di.inv[7] * g.y) + di.inv[8] * g.z};
+                g = normalize(g);
+                sh.ng[0] = g.x; sh.ng[1] = g.y; sh.ng[2] = g.z; sh.pad_ng = 0;
+            }
             DevTriLocal tl{};
             tl.p0[0] = pl[0].x; tl.p0[1] = pl[0].y; tl.p0[2] = pl[0].z; tl.p1x = pl[1].x;
             tl.p1yz[0] = pl[1].y; tl.p1yz[1] = pl[1].z; tl.p2xy[0] = pl[2].x; tl.p2xy[1] = pl[2].y; tl.p2z = pl[2].z;
