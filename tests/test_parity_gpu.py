@@ -802,3 +802,27 @@ def test_lowering_paths_agree_with_the_oracle(product, oracle, pkg, scene_id, st
         assert rmse <= 5e-4 and off <= 2, (mode, rmse, off)      # (the render-space any-hit of the two fallback paths leaves one sample of scene 4: 3.1e-4 / 1 pixel)
     rmse = float(np.sqrt(np.mean((frames["local"] - c) ** 2)))
     assert rmse <= FRAME_BAR[0] and int((np.abs(frames["local"] - c).max(axis=2) > 0.01).sum()) == 0
+
+
+def test_degenerate_triangles_stay_out_of_the_tree(product, oracle, pkg):
+    """math::intersect_triangle rejects a triangle whose cross product is exactly zero before anything else (ray.rs:49-56): it can never be
+    hit.  The product decides that once per triangle on the host (csrc/scene.cpp, on the vertices the traversal will test, with the
+    device's arithmetic), leaves such triangles out of the tree and runs the traversals' triangle test without the check (+1.5 ... 5 %).
+    Scene 33 = scene 25 with a collinear triple and a repeated vertex mixed into its first mesh: two triangles excluded, the frame scene
+    25's bit for bit in every lowering path, and the oracle's (which tests and rejects them like the reference) within the frame bar."""
+    frames = {}
+    for lowering in ("auto", "general"):
+        for sid in (25, 33):
+            sc = product.new_scene()
+            sc.debug_set_lowering(lowering)
+            cam = pkg.scenes.load_scene(sc, sid, 64, 48)
+            info = product.scene_info(sc)
+            assert f"degenerate={2 if sid == 33 else 0} " in info and " tris=2 " in info, info
+            frames[lowering, sid] = product.render(sc, cam, pkg.make_params(64, "nee", "sobol"))
+        assert np.array_equal(frames[lowering, 25], frames[lowering, 33])
+    so = oracle.new_scene()
+    cam_o = pkg.scenes.load_scene(so, 33, 64, 48)
+    oracle.set_faithful(so, False)
+    c = oracle.render(so, cam_o, pkg.make_params(64, "nee", "sobol"))
+    g = frames["auto", 33]
+    assert c.mean() > 0.01 and float(np.sqrt(np.mean((g - c) ** 2))) <= FRAME_BAR[0] and int((np.abs(g - c).max(axis=2) > 0.01).sum()) == 0

@@ -470,10 +470,15 @@ PT_DEV TriVerts load_tri(const DevTri* tris, uint32_t i, uint32_t* mclass = null
 PT_DEV f3 tri_origin(const DevScene& sc, f3 o) { return o + mk3(sc.tri_shift[0], sc.tri_shift[1], sc.tri_shift[2]); }
 
 // returns true and (t, b0, b1, b2) when the ray hits within (0, t_max]
+// DEGENERATE_CHECK false: the caller tests triangles of the tree, and the host left every triangle with a zero cross product out of it
+// (scene.cpp: decided on these very vertices with this arithmetic), so the first test of ray.rs:49-56 cannot fire
+template <bool DEGENERATE_CHECK = true>
 PT_DEV bool intersect_triangle(f3 ro, f3 rd, int kx, int ky, int kz, float sx, float sy, float sz, float t_max, const TriVerts& tv,
                                float& t_out, float& b0o, float& b1o, float& b2o) {
-    f3 c = cross(tv.p1 - tv.p0, tv.p2 - tv.p0);
-    if (dot(c, c) == 0.0f) return false;                                   // degenerate (:49-56)
+    if (DEGENERATE_CHECK) {
+        f3 c = cross(tv.p1 - tv.p0, tv.p2 - tv.p0);
+        if (dot(c, c) == 0.0f) return false;                               // degenerate (:49-56)
+    }
     f3 a0 = tv.p0 - ro, a1 = tv.p1 - ro, a2 = tv.p2 - ro;
     float p0x = comp(a0, kx), p0y = comp(a0, ky), p0z = comp(a0, kz);
     float p1x = comp(a1, kx), p1y = comp(a1, ky), p1z = comp(a1, kz);
@@ -595,7 +600,7 @@ PT_DEV void winner_hit(const DevScene& sc, f3 ro, f3 rd, const RaySetup& rs, uin
 #endif
     {   // the traversal's own test once more (same function, same inputs): in a tris_are_local scene that IS the reference's test
         const TriVerts tv = load_tri(sc.tris, tri, &hit.mclass);
-        intersect_triangle(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
+        intersect_triangle<false>(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, 3.402823466e+38f, tv, t, b0, b1, b2);
     }
     hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
 }
@@ -642,7 +647,7 @@ PT_DEV bool trace_closest(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_
                 TriVerts tv = load_tri(sc.tris, first + i);
                 float t, b0, b1, b2;
                 if (STATS) { st.tris_closest++; if (wave_leader()) st.w[1]++; }
-                if (intersect_triangle(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
+                if (intersect_triangle<false>(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_best, tv, t, b0, b1, b2)) {
                     if (!found || t < t_best) { found = true; t_best = t; hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; hit.tri = first + i; }
                 }
             }
@@ -688,7 +693,7 @@ PT_DEV bool trace_any(const DevScene& sc, f3 ro, f3 rd, float t_max, uint32_t* s
                 TriVerts tv = load_tri(sc.tris, first + i);
                 float t, b0, b1, b2;
                 if (STATS) { st.tris_shadow++; if (wave_leader()) st.w[3]++; }
-                if (intersect_triangle(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_max, tv, t, b0, b1, b2)) return true;
+                if (intersect_triangle<false>(tri_origin(sc, ro), rd, rs.kx, rs.ky, rs.kz, rs.sx, rs.sy, rs.sz, t_max, tv, t, b0, b1, b2)) return true;
             }
         }
         if (sp == 0) break;
@@ -904,7 +909,7 @@ PT_DEV bool trace_any_deferred(const DevScene& sc, f3 ro, f3 rd, float t_max, bo
             TriVerts tv = load_tri(sc.tris, tri);
             float t, b0, b1, b2;
             if (STATS) { st.tris_shadow++; if (wave_leader()) st.w[3]++; }
-            if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, tm, tv, t, b0, b1, b2))
+            if (intersect_triangle<false>(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, tm, tv, t, b0, b1, b2))
                 atomicOr(&L.occl[own >> 5], 1u << (own & 31u));
         }
         head += n;
@@ -1051,7 +1056,7 @@ PT_DEV bool trace_closest_coop(const DevScene& sc, f3 ro, f3 rd, bool want, uint
             TriVerts tv = load_tri(sc.tris, tri);
             float t, b0, b1, b2;
             if (STATS) { st.tris_closest++; if (wave_leader()) st.w[1]++; }
-            if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, t_lim, tv, t, b0, b1, b2)) {
+            if (intersect_triangle<false>(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, t_lim, tv, t, b0, b1, b2)) {
                 if (STATS) {    // exact ties in t (see trace_pair_coop)
                     const unsigned long long cur = L.best[own];
                     if ((uint32_t)(cur >> 32) == __float_as_uint(t) && (uint32_t)cur != tri) {
@@ -1289,7 +1294,7 @@ PT_DEV void trace_pair_coop(const DevScene& sc, f3 c_ro, f3 c_rd, bool c_want, f
             TriVerts tv = load_tri(sc.tris, tri);
             float t, b0, b1, b2;
             if (STATS) { if (any) { st.tris_shadow++; } else { st.tris_closest++; } if (wave_leader()) st.w[1]++; }
-            if (intersect_triangle(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, t_lim, tv, t, b0, b1, b2)) {
+            if (intersect_triangle<false>(o2, d2, (int)(kp & 3u), (int)((kp >> 2) & 3u), (int)(kp >> 4), sx, sy, sz, t_lim, tv, t, b0, b1, b2)) {
                 if (any) atomicOr(&L.occl[own >> 5], 1u << (own & 31u));
                 else {
                     if (STATS) {    // the merge keeps the LOWER triangle index on an exact tie, the reference the second child / earlier leaf item (bvh.rs:381-388): how often does it matter?

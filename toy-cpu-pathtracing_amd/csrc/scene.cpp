@@ -230,6 +230,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     std::vector<DevInstance> dinst(instances.size());
     std::vector<DevTri> tris_unordered;
     std::vector<DevTriLocal> local_unordered;
+    std::vector<uint8_t> deg_render, deg_local;      // cross product exactly zero (render-space / local vertices)
     bool all_shared = true, have_shared = false;
     float shared_iw[3] = {0, 0, 0}, shared_mw[3] = {0, 0, 0};
     std::vector<DevTriShade> shade_unordered;
@@ -350,6 +351,14 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
                 bt.c[a] = 0.5f * (bt.lo[a] + bt.hi[a]);
             }
             btris.push_back(bt);
+            // math::intersect_triangle rejects a triangle whose cross product is exactly zero (ray.rs:49-56) before anything else: such a
+            // triangle can never be hit, so it stays out of the tree and the traversals' triangle test does not repeat the check for every
+            // candidate (pt_device.hpp intersect_triangle<false>: +1.5 % on the Cornell scenes, +5 % on the 20 k-triangle hero of scene 17).
+            // Decided on the vertices the traversal will test, with the device's arithmetic.
+            {
+                const V3 cr = cross(p[1] - p[0], p[2] - p[0]);
+                deg_render.push_back(dot(cr, cr) == 0.0f ? 1 : 0);
+            }
             DevTriShade sh{};
             V3 pl[3];
             for (int k = 0; k < 3; ++k) pl[k] = V3{mesh.pos[3 * vi[k]], mesh.pos[3 * vi[k] + 1], mesh.pos[3 * vi[k] + 2]};
@@ -367,6 +376,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             tl.p1yz[0] = pl[1].y; tl.p1yz[1] = pl[1].z; tl.p2xy[0] = pl[2].x; tl.p2xy[1] = pl[2].y; tl.p2z = pl[2].z;
             tl.instance = (uint32_t)ii; tl.flags = di.identity; tl.mclass = dt.mclass;
             local_unordered.push_back(tl);
+            { const V3 cl = cross(pl[1] - pl[0], pl[2] - pl[0]); deg_local.push_back(dot(cl, cl) == 0.0f ? 1 : 0); }
             const float* n0 = &mesh.nrm[3 * vi[0]]; const float* n1 = &mesh.nrm[3 * vi[1]]; const float* n2 = &mesh.nrm[3 * vi[2]];
             sh.n0[0] = n0[0]; sh.n0[1] = n0[1]; sh.n0[2] = n0[2]; sh.n1x = n1[0];
             sh.n1yz[0] = n1[1]; sh.n1yz[1] = n1[2]; sh.n2xy[0] = n2[0]; sh.n2xy[1] = n2[1]; sh.n2z = n2[2];
@@ -410,6 +420,16 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
             if (dl.kind == LK_DIRECTIONAL) dl.area_sum = dl.intensity * (PI_F * radius * radius);
         }
     }
+    // which vertices will the traversal test?  (decided here, before the tree is built: mi355pt_scene_debug_set_lowering included)
+    const bool tris_local_mode = all_shared && have_shared && lowering < 1;
+    std::vector<uint32_t> kept;                       // build index -> triangle
+    {
+        const std::vector<uint8_t>& deg = tris_local_mode ? deg_local : deg_render;
+        std::vector<BuildTri> keep_b;
+        for (size_t i = 0; i < btris.size(); ++i) if (!deg[i]) { kept.push_back((uint32_t)i); keep_b.push_back(btris[i]); }
+        n_degenerate = btris.size() - kept.size();
+        btris.swap(keep_b);
+    }
     if (btris.empty()) { *err = "scene has no triangles"; return MI355PT_E_INVALID; }
     if (btris.size() > ((size_t)MAX_LEAF_TRIS << MAX_BUILD_DEPTH)) { *err = "too many triangles"; return MI355PT_E_INVALID; }   // 16.7 M: depth bound of the traversal stack
 
@@ -438,7 +458,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     std::vector<DevTri> tris(bvh.order.size());
     std::vector<DevTriShade> shade(bvh.order.size());
     std::vector<DevTriLocal> tris_local(bvh.order.size());
-    for (size_t i = 0; i < bvh.order.size(); ++i) { tris[i] = tris_unordered[bvh.order[i]]; shade[i] = shade_unordered[bvh.order[i]]; tris_local[i] = local_unordered[bvh.order[i]]; }
+    for (size_t i = 0; i < bvh.order.size(); ++i) { const uint32_t t = kept[bvh.order[i]]; tris[i] = tris_unordered[t]; shade[i] = shade_unordered[t]; tris_local[i] = local_unordered[t]; }
 
     // LUT pool, CMF, table (repacked to float4 cells), textures (RGBA8)
     std::vector<float> lut_pool;
@@ -588,8 +608,7 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     if ((rc = upload(this, shade, &dev.shade, err))) return rc;
     if ((rc = upload(this, dinst, &dev.instances, err))) return rc;
     if ((rc = upload(this, tris_local, &dev.tris_local, err))) return rc;
-    if (lowering >= 1) all_shared = false;                                   // (mi355pt_scene_debug_set_lowering: A/B and tests)
-    dev.tris_are_local = (all_shared && have_shared) ? 1u : 0u;
+    dev.tris_are_local = tris_local_mode ? 1u : 0u;                           // (lowering >= 1, mi355pt_scene_debug_set_lowering: never)
     dev.tris = dev.tris_are_local ? dev.tris_local : dev.tris_render;
     for (int k = 0; k < 3; ++k) { dev.tri_shift[k] = dev.tris_are_local ? shared_iw[k] : 0.0f; dev.shared_mw[k] = dev.tris_are_local ? shared_mw[k] : 0.0f; }
     dev.pad_mw = 0;
@@ -645,8 +664,8 @@ int SceneImpl::build(const mi355pt_camera* cam, const float* cmf4 /*470*4*/, std
     }
     {
         char tail[224];
-        std::snprintf(tail, sizeof(tail), " builder=%s bvh_ms=%.2f bvh_device_ms=%.2f collapse=%s collapse_ms=%.2f stack_need=%d/%d tri_space=%s", bvh_builder_used == MI355PT_BVH_GPU ? "gpu" : "host",
-                      bvh_build_ms, bvh_device_ms, collapse_method, collapse_ms, bvh4_stack_need, STACK_DEPTH, dev.tris_are_local ? "local" : "render");
+        std::snprintf(tail, sizeof(tail), " builder=%s bvh_ms=%.2f bvh_device_ms=%.2f collapse=%s collapse_ms=%.2f stack_need=%d/%d degenerate=%zu tri_space=%s", bvh_builder_used == MI355PT_BVH_GPU ? "gpu" : "host",
+                      bvh_build_ms, bvh_device_ms, collapse_method, collapse_ms, bvh4_stack_need, STACK_DEPTH, n_degenerate, dev.tris_are_local ? "local" : "render");
         info = "nodes4=" + std::to_string(bvh4_nodes) + " nodes=" + std::to_string(bvh.nodes.size()) + " tris=" + std::to_string(tris.size()) + " depth=" + std::to_string(bvh.max_depth) + tail;
     }
     built = true;

@@ -67,6 +67,7 @@ struct SceneImpl {
     size_t bvh4_nodes = 0;        // nodes of the collapsed tree (DevNode4)
     int bvh_builder = 0;          // MI355PT_BVH_AUTO / _HOST / _GPU (mi355pt_scene_set_bvh_builder)
     int bvh_builder_used = 1;     // what build() took
+    size_t n_degenerate = 0;      // triangles with an exactly zero cross product: never hit (ray.rs:49-56), left out of the tree
     int lowering = 0;             // mi355pt_scene_debug_set_lowering: 0 auto, 1 never the local triangle array, 2 also every instance through the full matrix path
     double collapse_ms = 0.0;     // host time of the 2-wide -> 4-wide collapse
     const char* collapse_method = "";   // "dp" or "greedy" (scene_info)

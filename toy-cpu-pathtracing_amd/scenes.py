@@ -258,6 +258,20 @@ def load_scene(scene, scene_id, width, height, tex_size=1024, build=True):
         scene.add_instance(scene.add_mesh(_asset("bunny")), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.8, 0.8))))
         _room(scene, p, with_light=False)
         cam = make_camera((0.0, 3.5, 6.0), (0.0, -1.0, -3.0), (0.0, 1.0, 0.0), width, height)
+    elif scene_id == 33:   # not a reference scene: scene 25's two triangles with DEGENERATE triangles mixed into the first mesh (a collinear
+        # triple and a repeated vertex: cross product exactly zero, math::intersect_triangle's first rejection, ray.rs:49-56).  The product leaves
+        # them out of the tree; the frame must be scene 25's bit for bit.
+        raw = assets.single_triangle()
+        raw = dict(pos=np.concatenate([raw["pos"], np.array([[0.0, 0.0, 0.0]], np.float32)]).astype(np.float32),
+                   nrm=np.concatenate([raw["nrm"], raw["nrm"][:1]]).astype(np.float32), uv=np.concatenate([raw["uv"], np.array([[0.5, 0.0]], np.float32)]).astype(np.float32),
+                   idx=np.array([[0, 1, 3], [0, 1, 2], [1, 1, 2]], dtype=np.uint32))
+        tri = assets.load_obj_semantics(raw)
+        tri2 = assets.load_obj_semantics(assets.single_triangle())
+        tri2 = dict(tri2); tri2["pos"] = (tri2["pos"] + np.array([0.5, 0.0, -1.0], dtype=np.float32)).astype(np.float32)
+        scene.add_instance(scene.add_mesh(tri), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.8, 0.5, 0.5))))
+        scene.add_instance(scene.add_mesh(tri2), scene.add_material(lambert(Spectrum.rgb_albedo_srgb(0.5, 0.8, 0.5))))
+        scene.add_delta_light(LIGHT_POINT, 10.0, Spectrum.lut(scene.add_lut470(p["cie_illum_d6500"])), _translate(0.5, 2.0, 2.5))
+        cam = make_camera((0.0, 1.5, 6.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), width, height)
     elif scene_id in (24, 25):   # not reference scenes: degenerate BVHs — one triangle (the root is a leaf), two triangles (one leaf) under a point light
         tri = assets.load_obj_semantics(assets.single_triangle())
         if scene_id == 25:
